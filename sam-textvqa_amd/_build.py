@@ -1,0 +1,61 @@
+"""Compile the HIP sources of this package into lib/libsam_hip.so for gfx950 (hipcc cross-compiles
+without a GPU).  Sources are hashed so repeated calls are no-ops; the .so stays in-tree so it
+travels with the repo snapshot to the GPU box."""
+import hashlib
+import os
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB_DIR = os.path.join(PKG, "lib")
+LIB = os.path.join(LIB_DIR, "libsam_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith((".hip", ".cpp", ".h")):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    inc = os.path.join(os.path.dirname(PKG), "include", "sam_hip.h")
+    if os.path.exists(inc):
+        h.update(open(inc, "rb").read())
+    return h.hexdigest()
+
+
+def build(force=False, verbose=False):
+    os.makedirs(LIB_DIR, exist_ok=True)
+    stamp = os.path.join(LIB_DIR, "libsam_hip.sha256")
+    dig = _digest()
+    if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return LIB
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
+        objs.append(obj)
+        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-I", os.path.join(os.path.dirname(PKG), "include"), "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n%s" % r.stdout.decode(errors="replace"))
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

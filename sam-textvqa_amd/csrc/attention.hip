@@ -1,0 +1,461 @@
+// Fused relation-masked multi-head attention for SA-M4C (gfx950).
+//
+// Replaces the eager-op cluster of /root/reference/sam/sa_m4c.py:563-598 (scores, min-combined
+// additive masks, softmax, fully-masked-row zeroing, dropout, PV, head merge) and its autograd,
+// for the spatial ('s') layers, the plain ('n') layers and TextBert alike: the per-(batch, head,
+// query) key allow-bitmask built by masks.hip carries ALL mask semantics, so these kernels only
+// test bits.  One workgroup = one (batch, head); head_dim = 64; whole K/V (or Q/dO) of the head
+// lives in LDS; softmax is single-pass in registers (N <= 384 keys).
+//
+// Orientation ("query per lane"): scores are produced as S^T tiles, D[key][query] with
+// query = lane&15 and keys 16t + 4*(lane>>4) + r, so a softmax row lives in 4 lanes x NKT*4
+// registers, P feeds the PV MFMA as its B operand with NO cross-lane movement, and V (stored
+// row-major [key][d] in LDS) is consumed through ds_read_b64_tr_b16.  The contraction index of
+// every second-stage MFMA is enumerated as k(g,e) = 32*s + 16*(e>>2) + 4*g + (e&3).
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;            // head dim
+constexpr int ROW_BYTES = HD * 2;  // one LDS tile row
+constexpr float LOG2E = 1.4426950408889634f;
+
+// byte offset of 16-byte chunk `ch` (0..7) of tile row `row`; the XOR keeps both ds_read_b128 row
+// reads (16 rows x same chunk) and ds_read_b64_tr_b16 column reads (8 rows x same 32-B block)
+// conflict-free ("LDS layouts").
+__device__ __forceinline__ int tile_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
+
+// stage rows [0,n_valid) of a [*, ld] bf16 matrix slice (64 columns) into an LDS tile of npad rows
+__device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, int64_t ld, int n_valid, int npad, int tid) {
+  for (int c = tid; c < npad * 8; c += 256) {
+    const int row = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + ch * 8);
+    *reinterpret_cast<uint4*>(lds + tile_off(row, ch)) = v;
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_row_frag(const unsigned char* tile, int row, int ch) {
+  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, ch));
+}
+// transposed fragment: lane (i,g) gets tile[32*s + 16*(e>>2) + 4*g + (e&3)][16*dt + i], e = 0..7
+__device__ __forceinline__ bf16x8 lds_col_frag(const unsigned char* tile, int s, int dt, int i, int g) {
+  const int row = 32 * s + 4 * g + (i >> 2);
+  const unsigned char* p = tile + tile_off(row, 2 * dt + ((i & 3) >> 1)) + (i & 1) * 8;
+  return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * ROW_BYTES));  // row+16 has the same swizzle
+}
+
+// Second-stage operands (P, dS) are fp32 values that must enter a bf16 MFMA.  A single bf16 rounding
+// costs ~2.5e-3*max in the worst output element (measured); splitting v = hi + lo (two MFMAs on the same
+// accumulator) brings the operand error to 2^-17, leaving only the bf16 rounding of the stored result.
+// The kernels are HBM-bound, the extra MFMAs are hidden.
+__device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& lo) {
+  typedef __attribute__((ext_vector_type(4))) unsigned u4;
+  u4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = pack_bf16x2(v[2 * j], v[2 * j + 1]);
+    l[j] = pack_bf16x2(v[2 * j] - bf_lo(h[j]), v[2 * j + 1] - bf_hi(h[j]));
+  }
+  hi = __builtin_bit_cast(bf16x8, h);
+  lo = __builtin_bit_cast(bf16x8, l);
+}
+
+struct AttnArgs {
+  const bf16_t* qkv;    // [B*N, 3*H*64]  q | k | v
+  const bf16_t* dout;   // [B*N, H*64]    (bwd only)
+  bf16_t* out_w;        // fwd output
+  bf16_t* dqkv;         // [B*N, 3*H*64]  (bwd output)
+  const uint32_t* allow;  // [B, Hm, N, NW]
+  int64_t allow_sb, allow_sh;
+  uint32_t* keep_w;       // [B, H, N, NW] fwd writes (dropout only)
+  const uint32_t* keep;   // bwd reads (nullptr = everything kept)
+  float* lse2_w;          // [B, H, N] fwd writes: log2-domain logsumexp of scale*s (+inf for dead rows)
+  const float* lse2;
+  float* delta;           // [B, H, N] bwd workspace: sum_k P*dP per query row
+  int B, N, H, NW, nkt;
+  float scale, scale_log2, p_drop, inv_keep;
+  unsigned thr16, seed_lo, seed_hi, off_lo, off_hi;
+};
+
+// --------------------------------------------------------------------------------------------
+// forward
+// --------------------------------------------------------------------------------------------
+template <int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NPAD = NKT * 16;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + NPAD * ROW_BYTES;
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int N = a.N, Dm = a.H * HD;
+  const int64_t ld = 3 * (int64_t)Dm;
+  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
+  stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  for (int mt = wave; mt * 16 < N; mt += 4) {
+    const int q = mt * 16 + i, qc = q < N ? q : N - 1;
+    bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
+    unsigned aw[NKT / 2];
+    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) aw[w] = ap[w];
+
+    f32x4 s[NKT];
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc, 0, 0, 0);
+      s[t] = acc;
+    }
+    // mask (bit test only), scale into the log2 domain, row max
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t) {
+      const unsigned nib = (aw[t >> 1] >> ((t & 1) * 16 + 4 * g)) & 0xFu;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ((nib >> r) & 1u) ? s[t][r] * a.scale_log2 : -INFINITY;
+        s[t][r] = v;
+        mx = fmaxf(mx, v);
+      }
+    }
+    mx = xgroup_max(mx);
+    const bool alive = mx > -INFINITY;  // reference: fully masked rows give exactly 0 (sa_m4c.py:574-584)
+    const float mref = alive ? mx : 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < NKT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float p = __builtin_amdgcn_exp2f(s[t][r] - mref);
+        s[t][r] = p;
+        sum += p;
+      }
+    sum = xgroup_sum(sum);
+    // attention-prob dropout (sa_m4c.py:588): applied after the row zeroing, before PV
+    if (a.thr16 != 0) {
+#pragma unroll
+      for (int w = 0; w < NKT / 2; ++w) {
+        const u32x4 rn = philox4x32_10((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
+        unsigned bits = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const unsigned r16 = (rr[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
+          const bool kept = r16 >= a.thr16;
+          if (!kept) s[2 * w + (e >> 2)][e & 3] = 0.f;
+          bits |= (kept ? 1u : 0u) << ((e >> 2) * 16 + 4 * g + (e & 3));
+        }
+        bits = xgroup_or(bits);
+        if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
+      }
+    }
+    bf16x8 pa[NKT / 2], pl[NKT / 2];
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) {
+      const float v8[8] = {s[2 * w][0], s[2 * w][1], s[2 * w][2], s[2 * w][3], s[2 * w + 1][0], s[2 * w + 1][1], s[2 * w + 1][2], s[2 * w + 1][3]};
+      split_pack8(v8, pa[w], pl[w]);
+    }
+    const float inv = alive ? a.inv_keep / sum : 0.f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int w = 0; w < NKT / 2; ++w) {
+        const bf16x8 vt = lds_col_frag(Vs, w, dt, i, g);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pa[w], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pl[w], acc, 0, 0, 0);
+      }
+      if (q < N) {
+        uint2 o = make_uint2(pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv));
+        *reinterpret_cast<uint2*>(a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 16 * dt + 4 * g) = o;
+      }
+    }
+    if (q < N && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx + __builtin_amdgcn_logf(sum) : INFINITY;
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// backward, pass 1: dQ (query per lane; K and V in LDS); also emits delta = rowsum(dO * O)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NPAD = a.nkt * 16;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + NPAD * ROW_BYTES;
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int N = a.N, Dm = a.H * HD;
+  const int64_t ld = 3 * (int64_t)Dm;
+  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
+  stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  for (int mt = wave; mt * 16 < N; mt += 4) {
+    const int q = mt * 16 + i, qc = q < N ? q : N - 1;
+    const int64_t orow = ((int64_t)b * N + qc) * Dm + h * HD;
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(a.dout + orow + 32 * ks + 8 * g);
+    }
+    const float lse = a.lse2[(int64_t)bh * N + qc];
+    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
+    const uint32_t* kp = a.keep ? a.keep + ((int64_t)bh * N + qc) * a.NW : nullptr;
+    // pass 1: delta = sum_k P_k * dP_k in fp32 from the recomputed probabilities (== rowsum(dO*O) of the
+    // exact forward; taking it from the bf16-stored O instead costs ~3e-3 relative error in dQ/dK)
+    float delta = 0.f;
+    for (int w = 0; w < a.nkt / 2; ++w) {
+      const unsigned aw = ap[w], kw = kp ? kp[w] : 0xffffffffu;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * w + half;
+        f32x4 acc_s = {0.f, 0.f, 0.f, 0.f}, acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          acc_s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc_s, 0, 0, 0);
+          acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dof[ks], acc_dp, 0, 0, 0);
+        }
+        const unsigned nb = ((aw & kw) >> (half * 16 + 4 * g)) & 0xFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if ((nb >> r) & 1u) delta += __builtin_amdgcn_exp2f(acc_s[r] * a.scale_log2 - lse) * acc_dp[r];
+      }
+    }
+    delta = xgroup_sum(delta) * a.inv_keep;
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int w = 0; w < a.nkt / 2; ++w) {
+      const unsigned aw = ap[w], kw = kp ? kp[w] : 0xffffffffu;
+      float dsv[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * w + half;
+        f32x4 acc_s = {0.f, 0.f, 0.f, 0.f}, acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          acc_s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc_s, 0, 0, 0);
+          acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dof[ks], acc_dp, 0, 0, 0);
+        }
+        const unsigned na = (aw >> (half * 16 + 4 * g)) & 0xFu, nk = (kw >> (half * 16 + 4 * g)) & 0xFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = ((na >> r) & 1u) ? __builtin_amdgcn_exp2f(acc_s[r] * a.scale_log2 - lse) : 0.f;
+          const float dpe = ((nk >> r) & 1u) ? acc_dp[r] * a.inv_keep : 0.f;
+          dsv[half * 4 + r] = p * (dpe - delta) * a.scale;
+        }
+      }
+      bf16x8 dsa, dsl;
+      split_pack8(dsv, dsa, dsl);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 kt_ = lds_col_frag(Ks, w, dt, i, g);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsa, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsl, dq[dt], 0, 0, 0);
+      }
+    }
+    if (q < N) {
+      bf16_t* dst = a.dqkv + ((int64_t)b * N + q) * ld + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf16x2(dq[dt][0], dq[dt][1]), pack_bf16x2(dq[dt][2], dq[dt][3]));
+      if (g == 0) a.delta[(int64_t)bh * N + q] = delta;
+    }
+  }
+}
+
+// --------------------------------------------------------------------------------------------
+// backward, pass 2: dK, dV (key per lane; Q, dO, lse, delta and the transposed bit rows in LDS)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int NPAD = a.nkt * 16, NW = a.NW;
+  unsigned char* Qs = smem;
+  unsigned char* dOs = Qs + NPAD * ROW_BYTES;
+  float* lse_s = reinterpret_cast<float*>(dOs + NPAD * ROW_BYTES);
+  float* del_s = lse_s + NPAD;
+  uint32_t* allowT = reinterpret_cast<uint32_t*>(del_s + NPAD);  // [NW][NPAD]
+  uint32_t* keepT = allowT + NW * NPAD;                           // [NW][NPAD]
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int N = a.N, Dm = a.H * HD;
+  const int64_t ld = 3 * (int64_t)Dm;
+  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  stage_tile(Qs, qbase, ld, N, NPAD, tid);
+  stage_tile(dOs, a.dout + (int64_t)b * N * Dm + h * HD, Dm, N, NPAD, tid);
+  for (int qi = tid; qi < NPAD; qi += 256) {
+    lse_s[qi] = qi < N ? a.lse2[(int64_t)bh * N + qi] : INFINITY;
+    del_s[qi] = qi < N ? a.delta[(int64_t)bh * N + qi] : 0.f;
+  }
+  const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh;
+  for (int c = tid; c < NPAD * NW; c += 256) {
+    const int qi = c / NW, w = c - qi * NW;
+    allowT[w * NPAD + qi] = qi < N ? ap[(int64_t)qi * NW + w] : 0u;
+    keepT[w * NPAD + qi] = (qi < N && a.keep) ? a.keep[((int64_t)bh * N + qi) * NW + w] : 0xffffffffu;
+  }
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  for (int kt = wave; kt * 16 < N; kt += 4) {
+    const int key = kt * 16 + i, kc = key < N ? key : N - 1;
+    bf16x8 kf[2], vf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      kf[ks] = *reinterpret_cast<const bf16x8*>(qbase + Dm + (int64_t)kc * ld + 32 * ks + 8 * g);
+      vf[ks] = *reinterpret_cast<const bf16x8*>(qbase + 2 * Dm + (int64_t)kc * ld + 32 * ks + 8 * g);
+    }
+    const int wsel = kt >> 1, bit = key & 31;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int s = 0; s < a.nkt / 2; ++s) {
+      float pv[8], dsv[8];
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * s + half;
+        f32x4 acc_s = {0.f, 0.f, 0.f, 0.f}, acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          acc_s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Qs, 16 * t + i, 4 * ks + g), kf[ks], acc_s, 0, 0, 0);
+          acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(dOs, 16 * t + i, 4 * ks + g), vf[ks], acc_dp, 0, 0, 0);
+        }
+        const int q4 = 16 * t + 4 * g;
+        const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + q4);
+        const f32x4 d4 = *reinterpret_cast<const f32x4*>(del_s + q4);
+        const uint4 a4 = *reinterpret_cast<const uint4*>(allowT + wsel * NPAD + q4);
+        const uint4 k4 = *reinterpret_cast<const uint4*>(keepT + wsel * NPAD + q4);
+        const unsigned aa[4] = {a4.x, a4.y, a4.z, a4.w}, kk[4] = {k4.x, k4.y, k4.z, k4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const bool allowed = (aa[r] >> bit) & 1u, kept = (kk[r] >> bit) & 1u;
+          const float p = allowed ? __builtin_amdgcn_exp2f(acc_s[r] * a.scale_log2 - l4[r]) : 0.f;
+          const float dpe = kept ? acc_dp[r] * a.inv_keep : 0.f;
+          pv[half * 4 + r] = kept ? p * a.inv_keep : 0.f;
+          dsv[half * 4 + r] = p * (dpe - d4[r]) * a.scale;
+        }
+      }
+      bf16x8 pa, pl, dsa, dsl;
+      split_pack8(pv, pa, pl);
+      split_pack8(dsv, dsa, dsl);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 dot_ = lds_col_frag(dOs, s, dt, i, g), qt_ = lds_col_frag(Qs, s, dt, i, g);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pa, dv[dt], 0, 0, 0);
+        dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dot_, pl, dv[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsa, dk[dt], 0, 0, 0);
+        dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qt_, dsl, dk[dt], 0, 0, 0);
+      }
+    }
+    if (key < N) {
+      bf16_t* dst = a.dqkv + ((int64_t)b * N + key) * ld + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        *reinterpret_cast<uint2*>(dst + Dm + 16 * dt) = make_uint2(pack_bf16x2(dk[dt][0], dk[dt][1]), pack_bf16x2(dk[dt][2], dk[dt][3]));
+        *reinterpret_cast<uint2*>(dst + 2 * Dm + 16 * dt) = make_uint2(pack_bf16x2(dv[dt][0], dv[dt][1]), pack_bf16x2(dv[dt][2], dv[dt][3]));
+      }
+    }
+  }
+}
+
+int pick_nkt(int N) {
+  const int need = (N + 15) / 16;
+  const int opts[] = {2, 4, 8, 12, 16, 24};
+  for (int o : opts)
+    if (o >= need) return o;
+  return -1;
+}
+
+int fill_common(AttnArgs& a, int B, int N, int H, int head_dim, float scale, float p_drop) {
+  SAM_REQUIRE(head_dim == HD, "sam_attn: head_dim must be 64 (got %d)", head_dim);
+  SAM_REQUIRE(B > 0 && N > 0 && H > 0, "sam_attn: empty problem B=%d N=%d H=%d", B, N, H);
+  SAM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sam_attn: p_drop=%f out of [0,1)", p_drop);
+  const int nkt = pick_nkt(N);
+  SAM_REQUIRE(nkt > 0, "sam_attn: N=%d exceeds the 384-key single-pass limit", N);
+  a.B = B; a.N = N; a.H = H; a.nkt = nkt; a.NW = nkt / 2;
+  a.scale = scale; a.scale_log2 = scale * LOG2E;
+  a.p_drop = p_drop;
+  a.thr16 = dropout_thr16(p_drop);
+  a.inv_keep = a.thr16 ? 1.0f / (1.0f - (float)a.thr16 / 65536.0f) : 1.0f;
+  return SAM_OK;
+}
+
+template <int NKT>
+int launch_fwd(const AttnArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(256), lds, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+}  // namespace
+
+extern "C" int sam_attn_words_per_row(int N) {
+  const int nkt = pick_nkt(N);
+  return nkt > 0 ? nkt / 2 : -1;
+}
+
+extern "C" int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                            int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
+                            uint32_t* keep, void* stream) {
+  AttnArgs a = {};
+  int rc = fill_common(a, B, N, H, head_dim, scale, p_drop);
+  if (rc) return rc;
+  SAM_REQUIRE(qkv && allow && out && lse2, "sam_attn_fwd: null pointer");
+  SAM_REQUIRE(a.thr16 == 0 || keep, "sam_attn_fwd: dropout needs a keep-bits buffer");
+  a.qkv = (const bf16_t*)qkv; a.out_w = (bf16_t*)out; a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h;
+  a.lse2_w = lse2; a.keep_w = keep;
+  a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.off_lo = (unsigned)offset; a.off_hi = (unsigned)(offset >> 32);
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.nkt) {
+    case 2: return launch_fwd<2>(a, st);
+    case 4: return launch_fwd<4>(a, st);
+    case 8: return launch_fwd<8>(a, st);
+    case 12: return launch_fwd<12>(a, st);
+    case 16: return launch_fwd<16>(a, st);
+    case 24: return launch_fwd<24>(a, st);
+  }
+  return SAM_ERR_UNSUPPORTED;
+}
+
+extern "C" int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow,
+                            int64_t allow_stride_b, int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim,
+                            float scale, float p_drop, void* dqkv, float* delta_ws, void* stream) {
+  AttnArgs a = {};
+  int rc = fill_common(a, B, N, H, head_dim, scale, p_drop);
+  if (rc) return rc;
+  SAM_REQUIRE(dout && qkv && lse2 && allow && dqkv && delta_ws, "sam_attn_bwd: null pointer");
+  SAM_REQUIRE(a.thr16 == 0 || keep, "sam_attn_bwd: dropout needs the keep bits written by sam_attn_fwd");
+  a.qkv = (const bf16_t*)qkv; a.dout = (const bf16_t*)dout; a.dqkv = (bf16_t*)dqkv;
+  a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h; a.keep = a.thr16 ? keep : nullptr;
+  a.lse2 = lse2; a.delta = delta_ws;
+  hipStream_t st = (hipStream_t)stream;
+  const int NPAD = a.nkt * 16;
+  const size_t lds1 = (size_t)2 * NPAD * ROW_BYTES;
+  const size_t lds2 = lds1 + (size_t)NPAD * 8 + (size_t)2 * a.NW * NPAD * 4;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    once = true;
+  }
+  attn_bwd_dq_kernel<<<dim3(B * H), dim3(256), lds1, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  attn_bwd_dkdv_kernel<<<dim3(B * H), dim3(256), lds2, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}

@@ -1,0 +1,101 @@
+// Shared device helpers for the SA-M4C hot-path kernels (gfx950 / CDNA4 only).
+// Hardware lane maps used below were pinned on an MI355X by tools/probes/probe_layouts.hip:
+//   v_mfma_f32_16x16x32_bf16:  A[i=l&15][k=8*(l>>4)+e]  B[k=8*(l>>4)+e][j=l&15]  D[i=4*(l>>4)+r][j=l&15]
+//   ds_read_b64_tr_b16: inside each 16-lane group, lane i receives column i of the 4x16 block whose
+//   row r is supplied (as four 8-byte pieces) by lanes 4r..4r+3.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;  // raw bf16 storage
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 hw_bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define SAM_OK 0
+#define SAM_ERR_ARG (-1)        // bad shape / alignment / null pointer
+#define SAM_ERR_UNSUPPORTED (-2)  // valid request this build has no kernel for
+
+extern "C" void sam_set_error(const char* fmt, ...);
+
+#define SAM_REQUIRE(cond, ...)                    \
+  do {                                            \
+    if (!(cond)) {                                \
+      sam_set_error(__VA_ARGS__);                 \
+      return SAM_ERR_ARG;                         \
+    }                                             \
+  } while (0)
+
+#define SAM_LAUNCH_CHECK()                                                       \
+  do {                                                                           \
+    hipError_t e_ = hipGetLastError();                                           \
+    if (e_ != hipSuccess) {                                                      \
+      sam_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); \
+      return (int)e_;                                                            \
+    }                                                                            \
+  } while (0)
+
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {  // RNE, v_cvt_pk_bf16_f32
+  f32x2 f = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, hw_bf16x2));
+}
+__device__ __forceinline__ bf16_t f2bf(float f) { return (bf16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bf_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __uint_as_float(u & 0xffff0000u); }
+
+// LDS transpose read: 4 bf16 (8 bytes) per lane, see header comment.
+__device__ __forceinline__ s16x4 lds_read_tr16(const void* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+}
+__device__ __forceinline__ bf16x8 cat4(s16x4 a, s16x4 b) {
+  bf16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return r;
+}
+
+// reductions across the four 16-lane groups that share (lane & 15)
+__device__ __forceinline__ float xgroup_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xgroup_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ unsigned xgroup_or(unsigned v) {
+  v |= __shfl_xor(v, 16);
+  return v | __shfl_xor(v, 32);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// Philox4x32-10 (Salmon et al. 2011), counter-based: same (key, counter) -> same bits in fwd and bwd.
+struct u32x4 { unsigned x, y, z, w; };
+__device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
+    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return {c0, c1, c2, c3};
+}
+// dropout threshold on 16-bit lanes of the Philox output: element kept iff rnd16 >= thr16
+__host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {
+  float t = p * 65536.0f + 0.5f;
+  return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (unsigned)t);
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}

@@ -1,0 +1,112 @@
+// Allow-bitmask builders: the whole mask algebra of the reference collapsed into one bit per
+// (batch, head, query, key), built ONCE per batch and reused by every layer's forward and backward.
+//
+//   sam_mask_bits_prefix_lm    <- MMT.forward's [B,1,N,N] additive mask, sa_m4c.py:805-844 (also TextBert's
+//                                 key-padding mask, sa_m4c.py:386-387, with n_dec = 0)
+//   sam_mask_bits_from_additive<- any caller-supplied additive [B,1,N,N] mask (module-level drop-in API)
+//   sam_mask_bits_spatial      <- SpatialBertSelfAttention's mask build + min-combine, sa_m4c.py:470-552,568:
+//                                 relation tensor int8 [B,Noo,Noo,R] (multi-hot, head-minor as the dataset
+//                                 emits it) + quadrant zeroing, AND-ed with the base bits
+// Bit k of word w of row (b,h,q) <=> key 32*w+k is visible.  Keys >= N always read 0.
+#include "common.h"
+
+namespace {
+
+__global__ void prefix_lm_kernel(const uint8_t* key_valid, int B, int n_enc, int n_dec, int NW, uint32_t* out) {
+  const int N = n_enc + n_dec;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * N * NW) return;
+  const int w = idx % NW, q = (idx / NW) % N, b = idx / ((int64_t)NW * N);
+  uint32_t bits = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int key = 32 * w + k;
+    bool ok = false;
+    if (key < n_enc) ok = key_valid[(int64_t)b * n_enc + key] != 0;   // every row sees valid encoder keys
+    else if (key < N) ok = (q >= n_enc) && (key <= q);                // decoder keys: causal, decoder rows only
+    bits |= (ok ? 1u : 0u) << k;
+  }
+  out[idx] = bits;
+}
+
+__global__ void from_additive_kernel(const float* mask, int B, int N, int NW, uint32_t* out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * N * NW) return;
+  const int w = idx % NW;
+  const int64_t row = idx / NW;  // b*N + q
+  uint32_t bits = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int key = 32 * w + k;
+    if (key < N && mask[row * N + key] > -5000.0f) bits |= 1u << k;  // reference masks are exactly 0 / -10000
+  }
+  out[idx] = bits;
+}
+
+// quadrant ids follow the reference's 3x3 numbering over (text, obj+ocr, dec) x (text, obj+ocr, dec)
+__device__ __forceinline__ int region_of(int x, int T, int n_oo) { return x < T ? 0 : (x < T + n_oo ? 1 : 2); }
+
+__global__ void spatial_kernel(const uint32_t* base, const int8_t* adj, int B, int N, int NW, int T, int n_oo, int R, int H,
+                               unsigned quadrant_bits, uint32_t* out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * N * NW) return;
+  const int w = idx % NW, q = (idx / NW) % N, b = idx / ((int64_t)NW * N);
+  const uint32_t base_bits = base[idx];
+  const int rq = region_of(q, T, n_oo);
+  uint32_t sp[16];
+#pragma unroll
+  for (int h = 0; h < 16; ++h) sp[h] = 0;
+  for (int k = 0; k < 32; ++k) {
+    const int key = 32 * w + k;
+    if (key >= N) break;
+    const int rk = region_of(key, T, n_oo);
+    const bool zeroed = (quadrant_bits >> (3 * rq + rk + 1)) & 1u;
+    if (zeroed) continue;
+    if (rq == 1 && rk == 1) {
+      const int8_t* p = adj + (((int64_t)b * n_oo + (q - T)) * n_oo + (key - T)) * R;
+#pragma unroll
+      for (int h = 0; h < 16; ++h)
+        if (h < R) sp[h] |= (p[h] != 0 ? 1u : 0u) << k;
+    } else {
+#pragma unroll
+      for (int h = 0; h < 16; ++h) sp[h] |= 1u << k;
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 16; ++h)
+    if (h < R) out[(((int64_t)b * H + h) * N + q) * NW + w] = base_bits & sp[h];
+  // heads >= R ("implicit" heads, sa_m4c.py:488-495) carry no spatial restriction
+  for (int h = R; h < H; ++h) out[(((int64_t)b * H + h) * N + q) * NW + w] = base_bits;
+}
+
+}  // namespace
+
+extern "C" int sam_mask_bits_prefix_lm(const uint8_t* key_valid, int B, int n_enc, int n_dec, int NW, uint32_t* out, void* stream) {
+  SAM_REQUIRE(key_valid && out, "sam_mask_bits_prefix_lm: null pointer");
+  const int N = n_enc + n_dec;
+  SAM_REQUIRE(B > 0 && n_enc >= 0 && n_dec >= 0 && N > 0 && NW * 32 >= N, "sam_mask_bits_prefix_lm: bad shape B=%d n_enc=%d n_dec=%d NW=%d", B, n_enc, n_dec, NW);
+  const int64_t total = (int64_t)B * N * NW;
+  prefix_lm_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(key_valid, B, n_enc, n_dec, NW, out);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_mask_bits_from_additive(const float* mask, int B, int N, int NW, uint32_t* out, void* stream) {
+  SAM_REQUIRE(mask && out, "sam_mask_bits_from_additive: null pointer");
+  SAM_REQUIRE(B > 0 && N > 0 && NW * 32 >= N, "sam_mask_bits_from_additive: bad shape");
+  const int64_t total = (int64_t)B * N * NW;
+  from_additive_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(mask, B, N, NW, out);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_mask_bits_spatial(const uint32_t* base, const int8_t* adj, int B, int N, int NW, int T, int n_oo, int R, int H,
+                                     unsigned quadrant_bits, uint32_t* out, void* stream) {
+  SAM_REQUIRE(base && adj && out, "sam_mask_bits_spatial: null pointer");
+  SAM_REQUIRE(B > 0 && N > 0 && NW * 32 >= N && T >= 0 && n_oo > 0 && T + n_oo <= N, "sam_mask_bits_spatial: bad shape N=%d T=%d n_oo=%d", N, T, n_oo);
+  SAM_REQUIRE(R >= 1 && R <= 16 && H >= R, "sam_mask_bits_spatial: need 1 <= R <= 16 and H >= R (R=%d H=%d)", R, H);
+  // legal quadrant ids are 1,2,4,7,8,9 (sa_m4c.py:505-549 raises ValueError on 3,5,6)
+  SAM_REQUIRE((quadrant_bits & ~((1u << 1) | (1u << 2) | (1u << 4) | (1u << 7) | (1u << 8) | (1u << 9))) == 0, "sam_mask_bits_spatial: illegal quadrant id in 0x%x", quadrant_bits);
+  const int64_t total = (int64_t)B * N * NW;
+  spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(base, adj, B, N, NW, T, n_oo, R, H, quadrant_bits, out);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}

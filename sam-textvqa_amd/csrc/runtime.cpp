@@ -1,0 +1,30 @@
+// Host-side runtime bits of libsam_hip.so: error string, version, device query.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+
+static thread_local char g_err[512] = "";
+
+extern "C" void sam_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* sam_last_error(void) { return g_err; }
+extern "C" int sam_abi_version(void) { return 1; }
+
+extern "C" int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len) {
+  hipDeviceProp_t p;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e == hipSuccess) e = hipGetDeviceProperties(&p, dev);
+  if (e != hipSuccess) {
+    sam_set_error("sam_device_info: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  if (cu_count) *cu_count = p.multiProcessorCount;
+  if (lds_per_cu_bytes) *lds_per_cu_bytes = (int)p.maxSharedMemoryPerMultiProcessor;
+  if (arch && arch_len > 0) snprintf(arch, arch_len, "%s", p.gcnArchName);
+  return 0;
+}

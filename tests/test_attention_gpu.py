@@ -1,0 +1,143 @@
+"""GPU parity: mask bit packers (bit-exact) and fused attention fwd/bwd vs the fp32 oracle."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sa_m4c_oracle as O
+from oracle import spatial_graph as SG
+from tests.golden import common as C
+from tests.util import assert_close_bf16, unpack_bits
+
+pytestmark = pytest.mark.gpu
+
+
+def _ops():
+    from sam_textvqa_amd import ops
+    return ops
+
+
+def make_problem(B, T, n_obj, n_ocr, n_dec, H=12, ctx=3, seed=0, full_valid=False):
+    rng = np.random.RandomState(seed)
+    n_oo = n_obj + n_ocr
+    n_txt_valid = [int(rng.randint(1, T + 1)) if T else 0 for _ in range(B)]
+    n_obj_valid = [n_obj if full_valid else int(rng.randint(1, n_obj + 1)) for _ in range(B)]
+    n_ocr_valid = [int(rng.randint(0, n_ocr + 1)) for _ in range(B)]
+    if B > 1:
+        n_ocr_valid[1] = 0          # a sample whose OCR tokens are all padding
+    kv = np.concatenate([C.pad_mask(n_txt_valid, T), C.pad_mask(n_obj_valid, n_obj), C.pad_mask(n_ocr_valid, n_ocr)], axis=1)
+    adj = []
+    for b in range(B):
+        boxes = np.concatenate([C.det_boxes("p%d.%d.obj" % (seed, b), n_obj_valid[b], n_obj, 0.21),
+                                C.det_boxes("p%d.%d.ocr" % (seed, b), n_ocr_valid[b], n_ocr, 0.08)], axis=0)
+        with np.errstate(all="ignore"):
+            adj.append(SG.compose(SG.relation_codes(boxes, 0.5), ctx))
+    adj = torch.from_numpy(np.stack(adj))[..., :H].contiguous()
+    return dict(B=B, T=T, n_oo=n_oo, n_dec=n_dec, N=T + n_oo + n_dec, H=H, key_valid=torch.from_numpy(kv), adj=adj)
+
+
+def oracle_attention(qkv, allow, B, H, scale, keep=None, inv_keep=1.0):
+    """fp32 restatement of sa_m4c.py:563-598 on a boolean allow mask; qkv [B*N, 3*H*64] float (requires_grad ok)."""
+    rows, three_d = qkv.shape
+    N, Dm = rows // B, three_d // 3
+    x = qkv.view(B, N, 3, H, Dm // H).permute(2, 0, 3, 1, 4)
+    q, k, v = x[0], x[1], x[2]
+    s = (q @ k.transpose(-1, -2)) * scale
+    s = s.masked_fill(~allow, -10000.0)          # same additive value as the reference
+    alive = allow.any(-1, keepdim=True).float()
+    p = torch.softmax(s, dim=-1) * alive
+    lse = torch.logsumexp(s.masked_fill(~allow, float("-inf")), dim=-1)
+    if keep is not None:
+        p = p * keep.float() * inv_keep
+    ctx = (p @ v).permute(0, 2, 1, 3).reshape(rows, Dm)
+    return ctx, lse
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 100, 50, 12), (2, 4, 10, 6, 3), (2, 20, 200, 100, 30)])
+@pytest.mark.parametrize("quadrants", [(1, 2), (4, 7, 8, 9), ()])
+def test_mask_bits_bit_exact(shape, quadrants):
+    ops = _ops()
+    pr = make_problem(*shape, seed=1)
+    dev = "cuda"
+    kv = pr["key_valid"].to(torch.uint8).to(dev)
+    base = ops.mask_bits_prefix_lm(kv, pr["n_dec"])
+    ref_plain = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], None, (), 1)
+    assert torch.equal(unpack_bits(base, pr["N"]), ref_plain)
+    assert (unpack_bits(base, base.shape[-1] * 32)[..., pr["N"]:] == 0).all()      # keys >= N read 0
+    sp = ops.mask_bits_spatial(base, pr["adj"].to(dev), pr["T"], pr["H"], quadrants)
+    ref = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], quadrants, pr["H"])
+    assert torch.equal(unpack_bits(sp, pr["N"]), ref)
+    # additive-mask entry point (module-level drop-in API) gives the same base bits
+    ext = O.MMT.extended_attention_mask(pr["key_valid"][:, :pr["T"]], pr["key_valid"][:, pr["T"]:pr["T"] + shape[2]],
+                                        pr["key_valid"][:, pr["T"] + shape[2]:], pr["n_dec"]).float().contiguous()
+    assert torch.equal(ops.mask_bits_from_additive(ext.to(dev)).cpu(), base.cpu())
+
+
+def test_mask_bits_rejects_bad_quadrant():
+    ops = _ops()
+    pr = make_problem(1, 4, 10, 6, 3)
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).cuda(), pr["n_dec"])
+    with pytest.raises(ValueError):
+        ops.mask_bits_spatial(base, pr["adj"].cuda(), pr["T"], 12, (3,))
+
+
+@pytest.mark.parametrize("shape,spatial", [((3, 20, 100, 50, 12), True), ((3, 20, 100, 50, 12), False), ((4, 20, 0, 0, 0), False),
+                                           ((2, 20, 200, 100, 30), True), ((2, 5, 30, 20, 7), True)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_fwd_bwd(shape, spatial, p_drop):
+    ops = _ops()
+    dev = "cuda"
+    B, T, n_obj, n_ocr, n_dec = shape
+    H, hd = 12, 64
+    if n_obj + n_ocr == 0:      # TextBert-style: key padding only
+        rng = np.random.RandomState(3)
+        kvm = torch.from_numpy(C.pad_mask([int(rng.randint(1, T + 1)) for _ in range(B)], T))
+        pr = dict(B=B, T=T, n_oo=0, n_dec=0, N=T, H=H, key_valid=kvm, adj=None)
+    else:
+        pr = make_problem(*shape, seed=2)
+    N = pr["N"]
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).to(dev), pr["n_dec"])
+    if spatial:
+        allow_bits = ops.mask_bits_spatial(base, pr["adj"].to(dev), pr["T"], H, (1, 2))
+        allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], (1, 2), H)
+    else:
+        allow_bits = base
+        allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], None, (), H)
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * N, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B * N, H * hd, generator=g).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(hd)
+
+    out, lse2, keep_bits = ops.attn_fwd(qkv.to(dev), allow_bits, B, H, scale, p_drop, seed=1234, offset=7)
+    keep, inv_keep = None, 1.0
+    if p_drop > 0:
+        keep = unpack_bits(keep_bits, N)
+        frac = keep[allow].float().mean().item()
+        assert abs(frac - (1 - p_drop)) < 0.01, frac
+        inv_keep = 1.0 / (1.0 - round(p_drop * 65536) / 65536.0)
+    qkv_ref = qkv.float().requires_grad_(True)
+    ref_out, ref_lse = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
+    assert_close_bf16(out, ref_out, name="attn out")
+    alive = allow.any(-1)
+    got_lse = lse2.cpu() * math.log(2.0)
+    assert torch.isinf(got_lse[~alive]).all() and (got_lse[~alive] > 0).all()
+    assert torch.allclose(got_lse[alive], ref_lse[alive], atol=2e-3, rtol=1e-4)
+    # fully masked rows (text rows of spatial layers) are EXACT zeros, as in the reference
+    dead_rows = (~alive).permute(0, 2, 1).reshape(B * N, H)
+    assert (out.cpu().float().view(B * N, H, hd)[dead_rows] == 0).all()
+
+    (ref_out * dout.float()).sum().backward()
+    dqkv = ops.attn_bwd(dout.to(dev), qkv.to(dev), lse2, allow_bits, keep_bits, B, H, scale, p_drop)
+    assert_close_bf16(dqkv, qkv_ref.grad, name="attn dqkv")
+
+
+def test_attention_error_paths():
+    ops = _ops()
+    from sam_textvqa_amd._capi import SamHipError
+    qkv = torch.zeros(8 * 4, 3 * 12 * 32, dtype=torch.bfloat16, device="cuda")      # head_dim 32: unsupported
+    allow = torch.zeros(4, 1, 8, 1, dtype=torch.int32, device="cuda")
+    with pytest.raises(SamHipError):
+        ops.attn_fwd(qkv, allow, 4, 12, 0.1)
+    with pytest.raises(SamHipError):
+        ops.attn_fwd(qkv.cpu(), allow, 4, 12, 0.1)
