@@ -1,0 +1,85 @@
+/* sam_hip.h — C ABI of libsam_hip.so: the MI355X (gfx950) hot path of SA-M4C training.
+ *
+ * The reference (yashkant/sam-textvqa) has no operator/FFI layer: its hot path is eager PyTorch inside
+ * sam/sa_m4c.py.  Each entry point below replaces one eager-op cluster of that file (cited per function,
+ * paths relative to /root/reference) and is what a maintainer would bind from Python (ctypes stub in
+ * INTEGRATION.md).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller; nothing is retained after the call returns;
+ *   - bf16 tensors are raw uint16 storage, row-major, leading dimensions in ELEMENTS and multiples of 8;
+ *   - calls enqueue on `stream` (a hipStream_t; NULL = default stream) and never synchronise;
+ *   - return 0 on success, a negative SAM_ERR_* for rejected arguments, a positive hipError_t for launch
+ *     failures; sam_last_error() gives the thread-local message.  No exceptions cross the boundary.
+ *   - stateless and re-entrant (one lazily-set function attribute per kernel is the only global state).
+ */
+#ifndef SAM_HIP_H
+#define SAM_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAM_ERR_ARG (-1)
+#define SAM_ERR_UNSUPPORTED (-2)
+
+int sam_abi_version(void);
+const char* sam_last_error(void);
+int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len);
+
+/* ---- allow-bit masks (built once per batch; bit k of word w of row (b,h,q) <=> key 32w+k visible) ---- */
+/* words per mask row for sequence length N (= padded keys / 32); -1 if N exceeds the fused kernel (384) */
+int sam_attn_words_per_row(int N);
+/* MMT.forward prefix-LM + causal decoder mask, sam/sa_m4c.py:805-844; TextBert padding mask :386-387 (n_dec=0).
+ * key_valid u8 [B,n_enc] -> out u32 [B,1,n_enc+n_dec,NW] */
+int sam_mask_bits_prefix_lm(const uint8_t* key_valid, int B, int n_enc, int n_dec, int NW, uint32_t* out, void* stream);
+/* any additive [B,1,N,N] fp32 mask (0 / -10000) as SpatialBertLayer.forward receives it, sam/sa_m4c.py:453-455 */
+int sam_mask_bits_from_additive(const float* mask, int B, int N, int NW, uint32_t* out, void* stream);
+/* SpatialBertSelfAttention mask build + min-combine, sam/sa_m4c.py:470-552,568.  adj int8 [B,n_oo,n_oo,R] multi-hot
+ * (head-minor, as sam/datasets/textvqa_dataset.py:378-409 emits it); quadrant_bits: bit q set <=> quadrant id q in
+ * attention_mask_quadrants (legal ids 1,2,4,7,8,9).  base u32 [B,1,N,NW] -> out u32 [B,H,N,NW] */
+int sam_mask_bits_spatial(const uint32_t* base, const int8_t* adj, int B, int N, int NW, int T, int n_oo, int R, int H,
+                          unsigned quadrant_bits, uint32_t* out, void* stream);
+
+/* ---- fused attention, sam/sa_m4c.py:563-598 (+ the plain BertSelfAttention of 'n' layers / TextBert) ----
+ * qkv bf16 [B*N, 3*H*64] (q|k|v, straight out of the fused QKV projection); allow as above with element strides
+ * (allow_stride_h = 0 broadcasts one mask over heads); out bf16 [B*N, H*64]; lse2 f32 [B,H,N] = log2-domain
+ * logsumexp of scale*q.k (+inf for fully masked rows, whose output is exactly 0 as sa_m4c.py:574-584);
+ * keep u32 [B,H,N,NW] receives the dropout keep bits when p_drop > 0 (Philox4x32-10 keyed by seed/offset). */
+int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                 int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
+                 uint32_t* keep, void* stream);
+/* autograd of the above: dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
+int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow, int64_t allow_stride_b,
+                 int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim, float scale, float p_drop,
+                 void* dqkv, float* delta_ws, void* stream);
+
+/* ---- bf16 MFMA GEMM with fused epilogues: the nn.Linear sites of the path ----
+ * C[M,N] = epilogue( sum_k A(m,k) * B(k,n) ), fp32 accumulate.
+ *   a_kcontig=1: A stored [M][lda] (k contiguous)   a_kcontig=0: A stored [K][lda] (m contiguous)
+ *   b_kcontig=1: B stored [N][ldb] (nn.Linear weight) b_kcontig=0: B stored [K][ldb] (n contiguous)
+ *   forward y = x W^T + b : (1,1);  dgrad dx = dy W : (1,0);  wgrad dW = dy^T x : (0,0) with A=dy, B=x swapped roles.
+ * Epilogues (sam/sa_m4c.py call sites; BertSelfOutput/BertIntermediate/BertOutput are pytorch-transformers):
+ *   SAM_EPI_NONE              C = acc (+ C when accumulate, fp32 C only)
+ *   SAM_EPI_BIAS              C = acc + bias[n]                                   query/key/value :554-556, classifier :275
+ *   SAM_EPI_BIAS_GELU         aux_out = acc + bias ; C = gelu_erf(aux_out)        BertIntermediate via :678
+ *   SAM_EPI_BIAS_DROPOUT_RES  C = dropout(acc + bias) + residual[m,n]             BertSelfOutput :653 / BertOutput :680 (pre-LN)
+ *   SAM_EPI_DGELU             C = acc * gelu_erf'(aux_in[m,n])                    backward of BertIntermediate
+ * bias may be NULL (treated as 0); dropout uses Philox4x32-10 on (row, col/8) so the backward regenerates it. */
+enum { SAM_EPI_NONE = 0, SAM_EPI_BIAS = 1, SAM_EPI_BIAS_GELU = 2, SAM_EPI_BIAS_DROPOUT_RES = 3, SAM_EPI_DGELU = 4 };
+typedef struct sam_gemm_desc {
+  int32_t M, N, K;
+  int32_t a_kcontig, b_kcontig;
+  int32_t c_is_f32, accumulate, epilogue;
+  const void* A; int64_t lda;
+  const void* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;
+  const void* residual; int64_t ldr;
+  void* aux_out; const void* aux_in; int64_t ld_aux;
+  float p_drop; uint64_t seed, offset;
+} sam_gemm_desc;
+int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

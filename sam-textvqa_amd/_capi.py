@@ -10,6 +10,19 @@ LIB_PATH = os.path.join(_PKG, "lib", "libsam_hip.so")
 
 _vp, _i, _i64, _u64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_uint
 
+class GemmDesc(C.Structure):
+    """mirror of `sam_gemm_desc` (include/sam_hip.h)"""
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("a_kcontig", C.c_int32), ("b_kcontig", C.c_int32),
+                ("c_is_f32", C.c_int32), ("accumulate", C.c_int32), ("epilogue", C.c_int32),
+                ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
+                ("bias", _vp), ("residual", _vp), ("ldr", _i64),
+                ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i64),
+                ("p_drop", _f), ("seed", _u64), ("offset", _u64)]
+
+
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)
+
 # name -> argtypes (all return int status except where noted)
 SIGNATURES = {
     "sam_attn_fwd": [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _f, _u64, _u64, _vp, _vp, _vp, _vp],
@@ -19,6 +32,7 @@ SIGNATURES = {
     "sam_mask_bits_from_additive": [_vp, _i, _i, _i, _vp, _vp],
     "sam_mask_bits_spatial": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp],
     "sam_abi_version": [],
+    "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
 }
 NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version"}
 

@@ -1,0 +1,253 @@
+// bf16 MFMA GEMM with fused epilogues for the nn.Linear sites of the SA-M4C path (gfx950).
+//
+// 128x128x64 block tile, 256 threads = 2x2 waves of 64x64, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
+// Operands are staged global -> registers -> LDS (next tile's loads are in flight during the MFMAs).
+// Either operand may be stored k-contiguous (fragments by ds_read_b128/b64) or k-strided (row index =
+// contraction index: fragments by ds_read_b64_tr_b16), which gives forward / dgrad / wgrad from one
+// template without any transpose pass through HBM.
+// The MFMA is issued "transposed" (rows = n, cols = m) so each lane ends up with 4 CONSECUTIVE n of one
+// output row: bias/residual/aux are 8- or 16-byte vector accesses and stores are 8 B (bf16) / 16 B (fp32).
+#include "common.h"
+#include "sam_hip.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+
+struct GemmArgs {
+  int M, N, K;
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;
+  const bf16_t* residual; int64_t ldr;
+  bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux;
+  int accumulate;
+  unsigned thr16; float inv_keep;
+  unsigned seed_lo, seed_hi, off_lo, off_hi;
+  int tiles_m, tiles_n;
+};
+
+// ---- LDS images --------------------------------------------------------------------------------
+// k-contiguous operand: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)
+__device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+// k-strided operand: [64 k][128 cols] bf16, 256-byte rows, chunk c (8 cols) stored at c ^ ((k&7)<<1)
+__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * 256 + ((chunk ^ ((krow & 7) << 1)) << 4); }
+
+template <bool KC>
+__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int rows, int k0, int K, int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + 256 * j;
+    r[j] = make_uint4(0, 0, 0, 0);
+    if (KC) {
+      const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
+      if (row < rows && k < K) r[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k);
+    } else {
+      const int k = k0 + (c >> 4), col = row0 + (c & 15) * 8;
+      if (k < K && col < rows) r[j] = *reinterpret_cast<const uint4*>(base + (int64_t)k * ld + col);
+    }
+  }
+}
+template <bool KC>
+__device__ __forceinline__ void store_tile(unsigned char* lds, const uint4 (&r)[4], int tid) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = tid + 256 * j;
+    const int off = KC ? kc_off(c >> 3, c & 7) : ks_off(c >> 4, c & 15);
+    *reinterpret_cast<uint4*>(lds + off) = r[j];
+  }
+}
+
+// fragment of 16 rows (row0..row0+15 of the operand's M/N index) x 32 k (step ks) for lane (i,g).
+// NATURAL k map (both operands k-contiguous): k = 32ks + 8g + e.
+// SPLIT k map (any operand k-strided):        k = 32ks + 16(e>>2) + 4g + (e&3)   -- both operands must agree.
+template <bool KC, bool SPLIT>
+__device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, int ks, int i, int g) {
+  if (KC) {
+    const int row = row0 + i;
+    if (!SPLIT) return *reinterpret_cast<const bf16x8*>(lds + kc_off(row, 4 * ks + g));
+    const int c0 = 4 * ks + (g >> 1), w = (g & 1) * 8;
+    const s16x4 lo = *reinterpret_cast<const s16x4*>(lds + kc_off(row, c0) + w);
+    const s16x4 hi = *reinterpret_cast<const s16x4*>(lds + kc_off(row, c0 + 2) + w);
+    return cat4(lo, hi);
+  } else {
+    const int krow = 32 * ks + 4 * g + (i >> 2);
+    const unsigned char* p = lds + ks_off(krow, (row0 >> 3) + ((i & 3) >> 1)) + (i & 1) * 8;
+    return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * 256));
+  }
+}
+
+template <typename OutT> struct Store4;
+template <> struct Store4<bf16_t> {
+  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int) {
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  }
+};
+template <> struct Store4<float> {
+  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int accumulate) {
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx);
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (accumulate) { const float4 c = *p; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+    *p = o;
+  }
+};
+
+template <bool AKC, bool BKC, int EPI, typename OutT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * BK * 2];
+  unsigned char* As = smem;
+  unsigned char* Bs = smem + BM * BK * 2;
+  constexpr bool SPLIT = !(AKC && BKC);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int wm = wave & 1, wn = wave >> 1;
+
+  // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles (n fastest) so the
+  // tiles that share an A panel / the whole B panel meet in one L2.
+  const int nblk = p.tiles_m * p.tiles_n;
+  int bid = blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+  }
+  const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  uint4 ra[4], rb[4];
+  load_tile<AKC>(ra, p.A, p.lda, m0, p.M, 0, p.K, tid);
+  load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
+  const int KT = (p.K + BK - 1) / BK;
+  for (int kt = 0; kt < KT; ++kt) {
+    store_tile<AKC>(As, ra, tid);
+    store_tile<BKC>(Bs, rb, tid);
+    __syncthreads();
+    if (kt + 1 < KT) {  // next tile's global loads fly during the MFMAs below
+      load_tile<AKC>(ra, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
+      load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 af[4], bf[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        af[t] = load_frag<AKC, SPLIT>(As, wm * 64 + t * 16, ks, i, g);
+        bf[t] = load_frag<BKC, SPLIT>(Bs, wn * 64 + t * 16, ks, i, g);
+      }
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm)
+          acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane owns rows m = m0 + wm*64 + tm*16 + i, columns n = n0 + wn*64 + tn*16 + 4g .. +3
+#pragma unroll
+  for (int tm = 0; tm < 4; ++tm) {
+    const int m = m0 + wm * 64 + tm * 16 + i;
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int tn = 0; tn < 4; ++tn) {
+      const int n = n0 + wn * 64 + tn * 16 + 4 * g;
+      if (n >= p.N) continue;
+      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+      if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+        if (p.bias) {
+          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+        }
+      }
+      if (EPI == SAM_EPI_BIAS_GELU) {
+        *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      }
+      if (EPI == SAM_EPI_DGELU) {
+        const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
+        v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
+        v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
+      }
+      if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+        if (p.thr16) {
+          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+          const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
+          v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
+          v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
+          v[2] = (hi & 0xffffu) >= p.thr16 ? v[2] * p.inv_keep : 0.f;
+          v[3] = (hi >> 16) >= p.thr16 ? v[3] * p.inv_keep : 0.f;
+        }
+        if (p.residual) {
+          const uint2 x = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldr + n);
+          v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
+        }
+      }
+      Store4<OutT>::st(p.C, (int64_t)m * p.ldc + n, v, p.accumulate);
+    }
+  }
+}
+
+template <bool AKC, bool BKC, int EPI, typename OutT>
+int launch(const GemmArgs& a, hipStream_t st) {
+  gemm_kernel<AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+}  // namespace
+
+extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
+  SAM_REQUIRE(d, "sam_gemm_bf16: null descriptor");
+  SAM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sam_gemm_bf16: empty problem %dx%dx%d", d->M, d->N, d->K);
+  SAM_REQUIRE(d->A && d->B && d->C, "sam_gemm_bf16: null operand");
+  SAM_REQUIRE(d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "sam_gemm_bf16: N, lda, ldb must be multiples of 8 (N=%d lda=%lld ldb=%lld)", d->N, (long long)d->lda, (long long)d->ldb);
+  SAM_REQUIRE(!d->a_kcontig || d->K % 8 == 0, "sam_gemm_bf16: K must be a multiple of 8 for k-contiguous A (K=%d)", d->K);
+  SAM_REQUIRE(!d->b_kcontig || d->K % 8 == 0, "sam_gemm_bf16: K must be a multiple of 8 for k-contiguous B (K=%d)", d->K);
+  SAM_REQUIRE(d->a_kcontig || d->M % 8 == 0, "sam_gemm_bf16: M must be a multiple of 8 for k-strided A (M=%d)", d->M);
+  SAM_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0) && ((uintptr_t)d->C % 16 == 0), "sam_gemm_bf16: operands must be 16-byte aligned");
+  SAM_REQUIRE(!d->accumulate || d->c_is_f32, "sam_gemm_bf16: accumulate needs an fp32 C");
+  SAM_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "sam_gemm_bf16: p_drop out of range");
+  GemmArgs a = {};
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.A = (const bf16_t*)d->A; a.lda = d->lda; a.B = (const bf16_t*)d->B; a.ldb = d->ldb; a.C = d->C; a.ldc = d->ldc;
+  a.bias = d->bias; a.residual = (const bf16_t*)d->residual; a.ldr = d->ldr;
+  a.aux_out = (bf16_t*)d->aux_out; a.aux_in = (const bf16_t*)d->aux_in; a.ld_aux = d->ld_aux;
+  a.accumulate = d->accumulate;
+  a.thr16 = dropout_thr16(d->p_drop);
+  a.inv_keep = a.thr16 ? 1.0f / (1.0f - (float)a.thr16 / 65536.0f) : 1.0f;
+  a.seed_lo = (unsigned)d->seed; a.seed_hi = (unsigned)(d->seed >> 32); a.off_lo = (unsigned)d->offset; a.off_hi = (unsigned)(d->offset >> 32);
+  a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
+  hipStream_t st = (hipStream_t)stream;
+  const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
+  const int e = d->epilogue;
+  if (e == SAM_EPI_BIAS_GELU) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
+  if (e == SAM_EPI_DGELU) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU needs aux_in");
+  if (e == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
+  if (lay == 3) {  // forward: x[M,K] . W[N,K]^T
+    if (d->c_is_f32) {
+      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, float>(a, st);
+      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, float>(a, st);
+    } else {
+      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, bf16_t>(a, st);
+      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, bf16_t>(a, st);
+      if (e == SAM_EPI_BIAS_GELU) return launch<true, true, SAM_EPI_BIAS_GELU, bf16_t>(a, st);
+      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, true, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st);
+    }
+  } else if (lay == 2) {  // dgrad: dy[M,N'] . W[N',K']
+    if (!d->c_is_f32) {
+      if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, bf16_t>(a, st);
+      if (e == SAM_EPI_DGELU) return launch<true, false, SAM_EPI_DGELU, bf16_t>(a, st);
+      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, false, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st);
+    } else if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, float>(a, st);
+  } else if (lay == 0) {  // wgrad: dy[rows,M]^T . x[rows,N]
+    if (d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, float>(a, st);
+    if (!d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, bf16_t>(a, st);
+  }
+  sam_set_error("sam_gemm_bf16: no kernel for layout (a_kcontig=%d,b_kcontig=%d) epilogue=%d c_is_f32=%d", d->a_kcontig, d->b_kcontig, e, d->c_is_f32);
+  return SAM_ERR_UNSUPPORTED;
+}

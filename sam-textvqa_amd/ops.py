@@ -96,3 +96,35 @@ def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0):
               capi.ptr(keep), batch, n, n_heads, d_model // n_heads, float(scale), float(p_drop), capi.ptr(dqkv), capi.ptr(delta),
               capi.stream_handle())
     return dqkv
+
+
+# ----------------------------------------------------------------------------- GEMM
+def _dp(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=None, out_dtype=BF16, epilogue=capi.EPI_NONE,
+         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0):
+    """C[M,N] = epilogue(sum_k A(m,k) B(k,n)); see include/sam_hip.h `sam_gemm_bf16` for layouts and epilogues.
+    a, b: 2-D bf16 tensors whose LAST dim is contiguous (row stride = leading dimension)."""
+    for t, nm in ((a, "A"), (b, "B")):
+        if not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1:
+            raise capi.SamHipError("gemm %s: need a 2-D bf16 GPU tensor with contiguous last dim" % nm)
+    M = m if m is not None else (a.shape[0] if a_kcontig else a.shape[1])
+    K = k if k is not None else (a.shape[1] if a_kcontig else a.shape[0])
+    N = n if n is not None else (b.shape[0] if b_kcontig else b.shape[1])
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    d = capi.GemmDesc()
+    d.M, d.N, d.K = M, N, K
+    d.a_kcontig, d.b_kcontig = int(a_kcontig), int(b_kcontig)
+    d.c_is_f32, d.accumulate, d.epilogue = int(out.dtype == torch.float32), int(accumulate), int(epilogue)
+    d.A, d.lda, d.B, d.ldb, d.C, d.ldc = a.data_ptr(), a.stride(0), b.data_ptr(), b.stride(0), out.data_ptr(), out.stride(0)
+    d.bias = _dp(bias)
+    d.residual, d.ldr = _dp(residual), (residual.stride(0) if residual is not None else 0)
+    d.aux_out, d.aux_in = _dp(aux_out), _dp(aux_in)
+    aux = aux_out if aux_out is not None else aux_in
+    d.ld_aux = aux.stride(0) if aux is not None else 0
+    d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
+    capi.call("sam_gemm_bf16", d, capi.stream_handle())
+    return out

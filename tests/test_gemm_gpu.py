@@ -1,0 +1,115 @@
+"""GPU parity: bf16 MFMA GEMM family (forward / dgrad / wgrad layouts, fused epilogues) vs fp32 matmul of
+the same bf16-rounded operands."""
+import math
+
+import pytest
+import torch
+
+from tests.util import assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from sam_textvqa_amd import _capi, ops
+    return ops, _capi
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def gelu(x):
+    return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
+
+
+SHAPES = [(728, 768, 768), (256, 128, 64), (130, 5000, 768), (200, 768, 3008), (1000, 2304, 768), (48, 768, 8), (1, 8, 8)]
+
+
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_forward_bias_and_f32(M, N, K):
+    ops, capi = _mods()
+    x, w = rnd((M, K), 1), rnd((N, K), 2, 0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(3))
+    ref = x.float() @ w.float().t() + b
+    y = ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS, bias=b.cuda())
+    assert_close_bf16(y, ref, name="bias bf16")
+    y32 = ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS, bias=b.cuda(), out_dtype=torch.float32)
+    assert_close_bf16(y32, ref, ulps=0, name="bias f32")
+    y0 = ops.gemm(x.cuda(), w.cuda())
+    assert_close_bf16(y0, x.float() @ w.float().t(), name="plain")
+
+
+def test_forward_gelu_and_dropout_residual():
+    ops, capi = _mods()
+    M, N, K = 728, 3072, 768
+    x, w = rnd((M, K), 4), rnd((N, K), 5, 0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(6)) * 0.1
+    pre_ref = x.float() @ w.float().t() + b
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    h = ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS_GELU, bias=b.cuda(), aux_out=pre)
+    assert_close_bf16(pre, pre_ref, name="pre-gelu")
+    assert_close_bf16(h, gelu(pre_ref), name="gelu")
+    # dense -> (+bias) -> dropout(p=0) -> + residual
+    w2, res = rnd((K, N), 7, 0.03), rnd((M, K), 8)
+    b2 = torch.randn(K, generator=torch.Generator().manual_seed(9)) * 0.1
+    hh = h.cpu()
+    ref = hh.float() @ w2.float().t() + b2 + res.float()
+    z = ops.gemm(h, w2.cuda(), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b2.cuda(), residual=res.cuda())
+    assert_close_bf16(z, ref, name="bias+res")
+    # with dropout: every element is either residual (dropped) or residual + (acc+bias)/(1-p)
+    p = 0.1
+    zd = ops.gemm(h, w2.cuda(), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b2.cuda(), residual=res.cuda(), p_drop=p, seed=11, offset=3).float().cpu()
+    inv = 1.0 / (1.0 - round(p * 65536) / 65536.0)
+    dense = hh.float() @ w2.float().t() + b2
+    kept_val = dense * inv + res.float()
+    is_drop = (zd - res.float()).abs() <= 2.0 ** -7 * res.float().abs() + 1e-6
+    is_kept = (zd - kept_val).abs() <= 1e-3 * kept_val.abs().max() + 2.0 ** -8 * kept_val.abs()
+    assert (is_drop | is_kept).all()
+    frac = 1.0 - (is_drop & ~is_kept).float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    zd2 = ops.gemm(h, w2.cuda(), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b2.cuda(), residual=res.cuda(), p_drop=p, seed=11, offset=3).float().cpu()
+    assert torch.equal(zd, zd2)     # counter-based: same (seed, offset) -> same mask
+
+
+@pytest.mark.parametrize("M,N,K", [(728, 768, 3072), (130, 768, 5000), (256, 64, 128), (200, 3008, 768)])
+def test_dgrad_layout(M, N, K):
+    """dx[M,N] = dy[M,K] . W[K,N]  (W stored [out=K][in=N]: contraction index is W's ROW index)"""
+    ops, capi = _mods()
+    dy, w = rnd((M, K), 10), rnd((K, N), 11, 0.05)
+    ref = dy.float() @ w.float()
+    dx = ops.gemm(dy.cuda(), w.cuda(), b_kcontig=False)
+    assert_close_bf16(dx, ref, name="dgrad")
+    pre = rnd((M, N), 12)
+    dxg = ops.gemm(dy.cuda(), w.cuda(), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre.cuda())
+    xp = pre.float()
+    dg = 0.5 * (1 + torch.erf(xp / math.sqrt(2))) + xp * torch.exp(-0.5 * xp * xp) / math.sqrt(2 * math.pi)
+    assert_close_bf16(dxg, ref * dg, name="dgrad*gelu'")
+    res = rnd((M, N), 13)
+    dxr = ops.gemm(dy.cuda(), w.cuda(), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=res.cuda())
+    assert_close_bf16(dxr, ref + res.float(), name="dgrad+res")
+
+
+@pytest.mark.parametrize("R,M,N", [(728, 768, 768), (182, 2304, 768), (130, 5000, 768), (1000, 768, 3072), (200, 768, 3008), (48, 768, 8)])
+def test_wgrad_layout(R, M, N):
+    """dW[M,N] = dy[R,M]^T . x[R,N]  (both operands k-strided), fp32 output with accumulate"""
+    ops, capi = _mods()
+    dy, x = rnd((R, M), 14), rnd((R, N), 15)
+    ref = dy.float().t() @ x.float()
+    dw = ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out_dtype=torch.float32)
+    assert_close_bf16(dw, ref, ulps=0, name="wgrad")
+    ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=True)
+    assert_close_bf16(dw, 2 * ref, ulps=0, name="wgrad accumulate")
+
+
+def test_strided_views_and_errors():
+    ops, capi = _mods()
+    big = rnd((300, 2304), 16).cuda()
+    w = rnd((768, 768), 17, 0.05).cuda()
+    y = ops.gemm(big[:, 768:1536], w)          # leading dimension 2304, K = 768
+    assert_close_bf16(y, big[:, 768:1536].float().cpu() @ w.float().cpu().t(), name="lda view")
+    with pytest.raises(capi.SamHipError):
+        ops.gemm(rnd((16, 12), 1).cuda(), rnd((16, 12), 2).cuda())      # K % 8 != 0
+    with pytest.raises(capi.SamHipError):
+        ops.gemm(big, w, out=torch.empty(300, 768, dtype=torch.bfloat16, device="cuda"), accumulate=True)
