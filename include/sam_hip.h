@@ -79,6 +79,48 @@ typedef struct sam_gemm_desc {
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
 
+/* ---- BertLayerNorm, sam/sa_m4c.py:1016-1028 (TF style, eps inside the sqrt, biased variance) ----
+ * x [M,D] bf16 or fp32 (x_is_f32) -> y bf16, plus per-row mean / rstd (fp32) for the backward. D % 4 == 0, D <= 2048. */
+int sam_layernorm_fwd(const void* x, int x_is_f32, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D, void* y,
+                      int64_t ldy, float* mean, float* rstd, void* stream);
+/* backward of y = LN(x): dx bf16 [M,D]; when dx_dropped != NULL also writes dropout(dx) with the SAME Philox
+ * (row, col/8) stream as SAM_EPI_BIAS_DROPOUT_RES used in the forward (the gradient of the dense in front of the
+ * residual add); dgamma/dbeta/dbias fp32 [D] (dbias = column sums of the dropped dx; may be NULL); accumulate: += .
+ * ws: sam_layernorm_bwd_ws_bytes(D) bytes of scratch. Deterministic two-stage reductions (no atomics). */
+int64_t sam_layernorm_bwd_ws_bytes(int D);
+int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int x_is_f32, int64_t ldx, const float* mean, const float* rstd,
+                      const float* gamma, int M, int D, void* dx, void* dx_dropped, int64_t ldo, float p_drop, uint64_t seed, uint64_t offset,
+                      float* dgamma, float* dbeta, float* dbias, int accumulate, float* ws, void* stream);
+/* bias gradients: out[n] (+)= sum_m x[m,n], x bf16 [M,N]; ws: sam_colsum_ws_bytes(N) */
+int64_t sam_colsum_ws_bytes(int N);
+int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* out, int accumulate, float* ws, void* stream);
+
+/* ---- M4CDecodingBCEWithMaskLoss, sam/task_utils.py:19-30: forward value AND analytic gradient in one pass ----
+ * scores arrive as the two blocks the model produces (classifier logits [R,V] and pointer scores [R,No], both fp32,
+ * R = B*S decoding rows); loss = sum(bce * mask[r]) / max(sum(mask),1); d_fixed bf16 [R,V], d_ocr fp32 [R,No], both
+ * already multiplied by grad_scale (1/world for data-parallel averaging). */
+int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, const float* targets, int64_t ld_t,
+                 const float* loss_mask, int R, int V, int No, float grad_scale, float* loss, void* d_fixed, int64_t ld_dfixed, float* d_ocr,
+                 int64_t ld_docr, void* stream);
+
+/* ---- OcrPtrNet bilinear scores, sam/sa_m4c.py:891-893: out[b,s,o] = scale*<q[b,s],k[b,o]> + (1-mask[b,o])*-10000 ----
+ * q bf16 [B,S,D], k bf16 [B,No,D] (already projected), mask u8 [B,No]; out fp32 with element strides (ld_out_b, ld_out_s) */
+int sam_ptr_scores_fwd(const void* q, const void* k, const uint8_t* ocr_mask, int B, int S, int No, int D, float scale, float* out,
+                       int64_t ld_out_b, int64_t ld_out_s, void* stream);
+int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const void* q, const void* k, int B, int S, int No, int D, float scale,
+                       void* dq, void* dk, void* stream);
+
+/* ---- optimizer step over ONE flat fp32 parameter buffer: clip_grad_norm_ + Adam, train.py:139-142, task_utils.py:33-57 ----
+ * sam_sumsq_f32: out[0] = sum g^2 (deterministic two-stage; every data-parallel rank gets the identical value).
+ * sam_adam_step: torch.optim.Adam semantics (bias-corrected, eps outside the sqrt); per-segment learning rates
+ * (param groups of SAM4C.get_optimizer_parameters, sa_m4c.py:349-371); gradient pre-scaled by
+ * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6)) when gnorm_sq != NULL; also refreshes the bf16 shadow weights. */
+int64_t sam_sumsq_ws_bytes(void);
+int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, void* stream);
+int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                  float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream);
+int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,8 +33,21 @@ SIGNATURES = {
     "sam_mask_bits_spatial": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp],
     "sam_abi_version": [],
     "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
+    "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],
+    "sam_layernorm_bwd": [_vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _f, _u64, _u64, _vp, _vp, _vp, _i, _vp, _vp],
+    "sam_layernorm_bwd_ws_bytes": [_i],
+    "sam_colsum_ws_bytes": [_i],
+    "sam_colsum_bf16": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp],
+    "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _i64, _vp],
+    "sam_ptr_scores_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i64, _i64, _vp],
+    "sam_ptr_scores_bwd": [_vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "sam_sumsq_ws_bytes": [],
+    "sam_sumsq_f32": [_vp, _i64, _vp, _vp, _vp],
+    "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],
+    "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version"}
+NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes"}
+RET_I64 = {"sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes"}
 
 _lib = None
 
@@ -54,7 +67,7 @@ def lib():
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = _i64 if name in RET_I64 else _i
         _lib = l
     return _lib
 

@@ -1,0 +1,479 @@
+// Row-wise / reduction kernels of the SA-M4C training path (gfx950): all HBM-bound, one pass each,
+// vectorised 8-byte (4 x bf16) or 16-byte accesses, 64-lane wave reductions.
+//   layernorm fwd/bwd  <- BertLayerNorm, sam/sa_m4c.py:1016-1028 (TF style: eps inside sqrt, biased variance);
+//                         bwd also applies the hidden-dropout mask of the preceding dense (BertSelfOutput /
+//                         BertOutput) and reduces dgamma / dbeta / dbias in the same pass
+//   colsum             <- bias gradients of the nn.Linear sites
+//   bce loss           <- M4CDecodingBCEWithMaskLoss, sam/task_utils.py:19-30 (forward + analytic gradient)
+//   ptr scores         <- OcrPtrNet.forward bilinear + additive mask, sam/sa_m4c.py:878-897
+//   adam / sumsq       <- clip_grad_norm_ + Adam step of train.py:139-142 over one flat parameter buffer
+#include "common.h"
+#include "sam_hip.h"
+
+namespace {
+
+constexpr int LN_PARTIAL_BLOCKS = 256;
+
+template <typename T> struct Ld4;
+template <> struct Ld4<bf16_t> {
+  static __device__ __forceinline__ void ld(const void* p, int64_t idx, float* v) {
+    const uint2 x = *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p) + idx);
+    v[0] = bf_lo(x.x); v[1] = bf_hi(x.x); v[2] = bf_lo(x.y); v[3] = bf_hi(x.y);
+  }
+};
+template <> struct Ld4<float> {
+  static __device__ __forceinline__ void ld(const void* p, int64_t idx, float* v) {
+    const float4 x = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + idx);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+  }
+};
+__device__ __forceinline__ void st4_bf16(void* p, int64_t idx, const float* v) {
+  *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+}
+
+// ------------------------------------------------------------------------------------------ layernorm
+template <typename InT, int NCH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D,
+                                                     void* y, int64_t ldy, float* mean_out, float* rstd_out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nchunk = D >> 2;
+  float v[NCH][4];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+    if (c < nchunk) Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, v[j]);
+    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+    if (lane + 64 * j < nchunk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * c), b4 = *reinterpret_cast<const float4*>(beta + 4 * c);
+      const float o[4] = {g4.x * ((v[j][0] - mean) * rstd) + b4.x, g4.y * ((v[j][1] - mean) * rstd) + b4.y,
+                          g4.z * ((v[j][2] - mean) * rstd) + b4.z, g4.w * ((v[j][3] - mean) * rstd) + b4.w};
+      st4_bf16(y, (int64_t)row * ldy + 4 * c, o);
+    }
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// ws layout: [LN_PARTIAL_BLOCKS][3][D]  (dgamma, dbeta, dbias partials)
+template <typename InT, int NCH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                                                     const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16,
+                                                     float inv_keep, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi, float* ws) {
+  __shared__ float red[4][64 * 4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nchunk = D >> 2;
+  float ag[NCH][4], ab[NCH][4], ad[NCH][4];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ag[j][e] = ab[j][e] = ad[j][e] = 0.f;
+  float gm[NCH][4];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
+    if (c < nchunk) Ld4<float>::ld(gamma, 4 * c, gm[j]);
+  }
+  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
+    const float mu = mean[row], rs = rstd[row];
+    float xh[NCH][4], g[NCH][4];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      float xv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (c < nchunk) {
+        Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv);
+        Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        xh[j][e] = c < nchunk ? (xv[e] - mu) * rs : 0.f;
+        g[j][e] = dv[e] * gm[j][e];
+        s1 += g[j][e];
+        s2 += g[j][e] * xh[j][e];
+        ag[j][e] += dv[e] * xh[j][e];
+        ab[j][e] += dv[e];
+      }
+    }
+    s1 = wave_sum(s1) / D;
+    s2 = wave_sum(s2) / D;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c >= nchunk) continue;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - s1 - xh[j][e] * s2);
+      st4_bf16(dx, (int64_t)row * ldo + 4 * c, o);
+      if (dxd) {
+        if (thr16) {  // same (row, col/8) Philox stream as the GEMM epilogue that produced the forward mask
+          const u32x4 rn = philox4x32_10((unsigned)row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
+          const unsigned lo = (c & 1) ? rn.z : rn.x, hi = (c & 1) ? rn.w : rn.y;
+          o[0] = (lo & 0xffffu) >= thr16 ? o[0] * inv_keep : 0.f;
+          o[1] = (lo >> 16) >= thr16 ? o[1] * inv_keep : 0.f;
+          o[2] = (hi & 0xffffu) >= thr16 ? o[2] * inv_keep : 0.f;
+          o[3] = (hi >> 16) >= thr16 ? o[3] * inv_keep : 0.f;
+        }
+        st4_bf16(dxd, (int64_t)row * ldo + 4 * c, o);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ad[j][e] += o[e];
+    }
+  }
+  // block reduction over the 4 waves, then one partial row per block
+#pragma unroll
+  for (int which = 0; which < 3; ++which) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      __syncthreads();
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[wave][lane * 4 + e] = which == 0 ? ag[j][e] : (which == 1 ? ab[j][e] : ad[j][e]);
+      __syncthreads();
+      if (wave == 0 && c < nchunk) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = red[0][lane * 4 + e] + red[1][lane * 4 + e] + red[2][lane * 4 + e] + red[3][lane * 4 + e];
+        *reinterpret_cast<float4*>(ws + ((int64_t)blockIdx.x * 3 + which) * D + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+}
+
+// out[c] (+)= sum_r ws[r*stride + c]   (deterministic order)
+__global__ void partial_finalize_kernel(const float* ws, int nrows, int64_t stride, int ncols, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= ncols) return;
+  float s = 0.f;
+  for (int r = 0; r < nrows; ++r) s += ws[(int64_t)r * stride + c];
+  out[c] = accumulate ? out[c] + s : s;
+}
+
+// ------------------------------------------------------------------------------------------ colsum
+constexpr int COLSUM_CHUNKS = 64;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* x, int64_t ldx, int M, int N, float* ws) {
+  const int c4 = blockIdx.x * 256 + threadIdx.x;  // group of 4 columns
+  if (c4 * 4 >= N) return;
+  const int rows_per = (M + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
+  const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int r = r0; r < r1; ++r) {
+    float v[4];
+    Ld4<bf16_t>::ld(x, (int64_t)r * ldx + 4 * c4, v);
+    a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
+  }
+  *reinterpret_cast<float4*>(ws + (int64_t)blockIdx.y * N + 4 * c4) = make_float4(a[0], a[1], a[2], a[3]);
+}
+
+// ------------------------------------------------------------------------------------------ BCE loss
+// loss = sum_{r,c} bce(x, t) * mask[r] / max(sum(mask), 1);  d x = (sigmoid(x) - t) * mask[r] * gscale / count
+__global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ldf, const float* ocr, int64_t ldoc, const float* targets, int64_t ldt,
+                                                  const float* mask, int R, int V, int No, float gscale, float* loss, bf16_t* d_fixed, int64_t lddf,
+                                                  float* d_ocr, int64_t lddo) {
+  __shared__ float sred[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float cnt = 0.f;
+  for (int r = threadIdx.x; r < R; r += 256) cnt += mask[r];
+  cnt = wave_sum(cnt);
+  if (lane == 0) sred[wave] = cnt;
+  __syncthreads();
+  cnt = fmaxf(sred[0] + sred[1] + sred[2] + sred[3], 1.0f);
+  __syncthreads();
+  const float inv_cnt = 1.0f / cnt;
+  const int W = V + No;
+  float acc = 0.f;
+  const int64_t total = (int64_t)R * W;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int r = idx / W, c = idx - (int64_t)r * W;
+    const float m = mask[r];
+    const float x = c < V ? fixed[(int64_t)r * ldf + c] : ocr[(int64_t)r * ldoc + (c - V)];
+    const float t = targets[(int64_t)r * ldt + c];
+    const float e = __expf(-fabsf(x));
+    acc += m * (fmaxf(x, 0.f) - x * t + log1pf(e));
+    const float sig = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
+    const float gx = (sig - t) * m * inv_cnt * gscale;
+    if (c < V) d_fixed[(int64_t)r * lddf + c] = f2bf(gx);
+    else d_ocr[(int64_t)r * lddo + (c - V)] = gx;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) sred[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (sred[0] + sred[1] + sred[2] + sred[3]) * inv_cnt);
+}
+
+// ------------------------------------------------------------------------------------------ pointer network
+// scores[b,s,o] = scale * <q[b,s,:], k[b,o,:]> + (1 - mask[b,o]) * -10000     (fp32, literal -10000 kept: it is an OUTPUT)
+__global__ __launch_bounds__(256) void ptr_fwd_kernel(const bf16_t* q, const bf16_t* k, const uint8_t* mask, int S, int No, int D, float scale,
+                                                      float* out, int64_t ldo_b, int64_t ldo_s) {
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* qb = q + (int64_t)b * S * D;
+  const bf16_t* kb = k + (int64_t)b * No * D;
+  for (int p = wave; p < S * No; p += 4) {  // one wave per (s, o) pair: 64-lane dot product over D
+    const int s = p / No, o = p - s * No;
+    float acc = 0.f;
+    for (int c = lane; c * 4 < D; c += 64) {
+      float a[4], bb[4];
+      Ld4<bf16_t>::ld(qb, (int64_t)s * D + 4 * c, a);
+      Ld4<bf16_t>::ld(kb, (int64_t)o * D + 4 * c, bb);
+      acc += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[(int64_t)b * ldo_b + (int64_t)s * ldo_s + o] = acc * scale + (mask[(int64_t)b * No + o] ? 0.f : -10000.0f);
+  }
+}
+// dq[b,s,:] = scale * sum_o ds[b,s,o] k[b,o,:] ; dk[b,o,:] = scale * sum_s ds[b,s,o] q[b,s,:]
+__global__ __launch_bounds__(256) void ptr_bwd_kernel(const float* ds, int64_t ld_b, int64_t ld_s, const bf16_t* q, const bf16_t* k, int S, int No, int D,
+                                                      float scale, bf16_t* dq, bf16_t* dk) {
+  extern __shared__ float sds[];  // [S*No]
+  const int b = blockIdx.x;
+  for (int p = threadIdx.x; p < S * No; p += 256) sds[p] = ds[(int64_t)b * ld_b + (int64_t)(p / No) * ld_s + (p % No)] * scale;
+  __syncthreads();
+  const bf16_t* qb = q + (int64_t)b * S * D;
+  const bf16_t* kb = k + (int64_t)b * No * D;
+  for (int c = threadIdx.x; c * 4 < D; c += 256) {
+    for (int s = 0; s < S; ++s) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int o = 0; o < No; ++o) {
+        float kv[4];
+        Ld4<bf16_t>::ld(kb, (int64_t)o * D + 4 * c, kv);
+        const float w = sds[s * No + o];
+        a[0] += w * kv[0]; a[1] += w * kv[1]; a[2] += w * kv[2]; a[3] += w * kv[3];
+      }
+      st4_bf16(dq, ((int64_t)b * S + s) * D + 4 * c, a);
+    }
+    for (int o = 0; o < No; ++o) {
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < S; ++s) {
+        float qv[4];
+        Ld4<bf16_t>::ld(qb, (int64_t)s * D + 4 * c, qv);
+        const float w = sds[s * No + o];
+        a[0] += w * qv[0]; a[1] += w * qv[1]; a[2] += w * qv[2]; a[3] += w * qv[3];
+      }
+      st4_bf16(dk, ((int64_t)b * No + o) * D + 4 * c, a);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ optimizer
+constexpr int SUMSQ_BLOCKS = 1024;
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, int64_t n, float* partial) {
+  __shared__ float sred[4];
+  float acc = 0.f;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(g)[i];
+    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = g[(n4 << 2) + threadIdx.x]; acc += t * t; }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, int nblk, float* out) {
+  __shared__ float sred[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[i];
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (sred[0] + sred[1]) + (sred[2] + sred[3]);
+}
+
+struct AdamSegs { int64_t end[8]; float lr[8]; int n; };
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, int64_t n, AdamSegs segs, float b1, float b2,
+                                                   float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm) {
+  float clip = 1.0f;
+  if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));   // torch clip_grad_norm_
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int64_t e0 = i << 2;
+    float lr = 0.f;
+#pragma unroll
+    for (int s = 7; s >= 0; --s)
+      if (s < segs.n && e0 < segs.end[s]) lr = segs.lr[s];
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    const float gg[4] = {g4.x * clip, g4.y * clip, g4.z * clip, g4.w * clip};
+    float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      mm[e] = b1 * mm[e] + (1.0f - b1) * gg[e];
+      vv[e] = b2 * vv[e] + (1.0f - b2) * gg[e] * gg[e];
+      const float denom = sqrtf(vv[e]) * rsqrt_bc2 + eps;
+      pp[e] -= (lr / bc1) * (mm[e] / denom);
+    }
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3]));
+  }
+}
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* y, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    reinterpret_cast<uint2*>(y)[i] = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+  }
+}
+
+template <typename InT>
+int ln_fwd_dispatch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D,
+                    void* y, int64_t ldy, float* mean, float* rstd) {
+#define LN_FWD_CASE(NC) case NC: ln_fwd_kernel<InT, NC><<<grid, dim3(256), 0, st>>>(x, ldx, gamma, beta, eps, M, D, y, ldy, mean, rstd); break;
+  switch (nch) { LN_FWD_CASE(1) LN_FWD_CASE(2) LN_FWD_CASE(3) LN_FWD_CASE(4) LN_FWD_CASE(5) LN_FWD_CASE(6) LN_FWD_CASE(7) LN_FWD_CASE(8) default: return SAM_ERR_UNSUPPORTED; }
+#undef LN_FWD_CASE
+  return SAM_OK;
+}
+template <typename InT>
+int ln_bwd_dispatch(int nch, dim3 grid, hipStream_t st, const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
+                    const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16, float inv_keep, uint64_t seed, uint64_t offset, float* ws) {
+#define LN_BWD_CASE(NC) case NC: ln_bwd_kernel<InT, NC><<<grid, dim3(256), 0, st>>>(dy, ldd, x, ldx, mean, rstd, gamma, M, D, dx, dxd, ldo, thr16, inv_keep, \
+      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), ws); break;
+  switch (nch) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6) LN_BWD_CASE(7) LN_BWD_CASE(8) default: return SAM_ERR_UNSUPPORTED; }
+#undef LN_BWD_CASE
+  return SAM_OK;
+}
+
+}  // namespace
+
+extern "C" int sam_layernorm_fwd(const void* x, int x_is_f32, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D, void* y,
+                                 int64_t ldy, float* mean, float* rstd, void* stream) {
+  SAM_REQUIRE(x && gamma && beta && y && mean && rstd, "sam_layernorm_fwd: null pointer");
+  SAM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && ldy % 4 == 0, "sam_layernorm_fwd: need D %% 4 == 0, D <= 2048 (M=%d D=%d)", M, D);
+  const int nch = (D / 4 + 63) / 64;
+  const dim3 grid((M + 3) / 4);
+  int rc = x_is_f32 ? ln_fwd_dispatch<float>(nch, grid, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, D, y, ldy, mean, rstd)
+                    : ln_fwd_dispatch<bf16_t>(nch, grid, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, D, y, ldy, mean, rstd);
+  if (rc) return rc;
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int64_t sam_layernorm_bwd_ws_bytes(int D) { return (int64_t)LN_PARTIAL_BLOCKS * 3 * D * sizeof(float); }
+
+extern "C" int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int x_is_f32, int64_t ldx, const float* mean, const float* rstd,
+                                 const float* gamma, int M, int D, void* dx, void* dx_dropped, int64_t ldo, float p_drop, uint64_t seed, uint64_t offset,
+                                 float* dgamma, float* dbeta, float* dbias, int accumulate, float* ws, void* stream) {
+  SAM_REQUIRE(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && ws, "sam_layernorm_bwd: null pointer");
+  SAM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && ldd % 4 == 0 && ldo % 4 == 0, "sam_layernorm_bwd: bad shape M=%d D=%d", M, D);
+  SAM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sam_layernorm_bwd: p_drop out of range");
+  SAM_REQUIRE(!dbias || dx_dropped || p_drop == 0.f, "sam_layernorm_bwd: dbias with dropout needs dx_dropped");
+  const unsigned thr16 = dropout_thr16(p_drop);
+  const float inv_keep = thr16 ? 1.0f / (1.0f - (float)thr16 / 65536.0f) : 1.0f;
+  const int nch = (D / 4 + 63) / 64;
+  const int nblk = min(LN_PARTIAL_BLOCKS, (M + 3) / 4);
+  hipStream_t st = (hipStream_t)stream;
+  bf16_t* dxd = (bf16_t*)dx_dropped;
+  int rc = x_is_f32 ? ln_bwd_dispatch<float>(nch, dim3(nblk), st, (const bf16_t*)dy, ldd, x, ldx, mean, rstd, gamma, M, D, (bf16_t*)dx, dxd, ldo, thr16, inv_keep, seed, offset, ws)
+                    : ln_bwd_dispatch<bf16_t>(nch, dim3(nblk), st, (const bf16_t*)dy, ldd, x, ldx, mean, rstd, gamma, M, D, (bf16_t*)dx, dxd, ldo, thr16, inv_keep, seed, offset, ws);
+  if (rc) return rc;
+  SAM_LAUNCH_CHECK();
+  const dim3 fg((D + 255) / 256);
+  partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, dgamma, accumulate);
+  partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws + D, nblk, 3 * (int64_t)D, D, dbeta, accumulate);
+  // dbias of the dense in front of this LN = column sums of the (dropout-masked) dx
+  if (dbias) {
+    partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws + 2 * D, nblk, 3 * (int64_t)D, D, dbias, accumulate);
+  }
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int64_t sam_colsum_ws_bytes(int N) { return (int64_t)COLSUM_CHUNKS * N * sizeof(float); }
+
+extern "C" int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* out, int accumulate, float* ws, void* stream) {
+  SAM_REQUIRE(x && out && ws, "sam_colsum_bf16: null pointer");
+  SAM_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "sam_colsum_bf16: need N %% 4 == 0 (M=%d N=%d)", M, N);
+  hipStream_t st = (hipStream_t)stream;
+  colsum_partial_kernel<<<dim3((N / 4 + 255) / 256, COLSUM_CHUNKS), dim3(256), 0, st>>>((const bf16_t*)x, ldx, M, N, ws);
+  partial_finalize_kernel<<<dim3((N + 255) / 256), dim3(256), 0, st>>>(ws, COLSUM_CHUNKS, N, N, out, accumulate);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, const float* targets, int64_t ld_t,
+                            const float* loss_mask, int R, int V, int No, float grad_scale, float* loss, void* d_fixed, int64_t ld_dfixed, float* d_ocr,
+                            int64_t ld_docr, void* stream) {
+  SAM_REQUIRE(fixed_scores && ocr_scores && targets && loss_mask && loss && d_fixed && d_ocr, "sam_bce_loss: null pointer");
+  SAM_REQUIRE(R > 0 && V > 0 && No >= 0, "sam_bce_loss: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
+  if (e != hipSuccess) { sam_set_error("sam_bce_loss: memset: %s", hipGetErrorString(e)); return (int)e; }
+  const int64_t total = (int64_t)R * (V + No);
+  const int blocks = (int)min((int64_t)2048, (total + 255) / 256);
+  bce_kernel<<<dim3(blocks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, loss,
+                                                 (bf16_t*)d_fixed, ld_dfixed, d_ocr, ld_docr);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_ptr_scores_fwd(const void* q, const void* k, const uint8_t* ocr_mask, int B, int S, int No, int D, float scale, float* out,
+                                  int64_t ld_out_b, int64_t ld_out_s, void* stream) {
+  SAM_REQUIRE(q && k && ocr_mask && out, "sam_ptr_scores_fwd: null pointer");
+  SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0, "sam_ptr_scores_fwd: bad shape");
+  ptr_fwd_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+extern "C" int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const void* q, const void* k, int B, int S, int No, int D, float scale,
+                                  void* dq, void* dk, void* stream) {
+  SAM_REQUIRE(dscores && q && k && dq && dk, "sam_ptr_scores_bwd: null pointer");
+  SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0 && (size_t)S * No * 4 <= 64 * 1024, "sam_ptr_scores_bwd: bad shape");
+  ptr_bwd_kernel<<<dim3(B), dim3(256), (size_t)S * No * sizeof(float), (hipStream_t)stream>>>(dscores, ld_b, ld_s, (const bf16_t*)q, (const bf16_t*)k, S, No, D,
+                                                                                          scale, (bf16_t*)dq, (bf16_t*)dk);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int64_t sam_sumsq_ws_bytes(void) { return (int64_t)SUMSQ_BLOCKS * sizeof(float); }
+extern "C" int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, void* stream) {
+  SAM_REQUIRE(g && out && ws && n > 0 && ((uintptr_t)g % 16 == 0), "sam_sumsq_f32: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  const int blocks = (int)min((int64_t)SUMSQ_BLOCKS, ((n >> 2) + 255) / 256 + 1);
+  sumsq_partial_kernel<<<dim3(blocks), dim3(256), 0, st>>>(g, n, ws);
+  sumsq_final_kernel<<<dim3(1), dim3(256), 0, st>>>(ws, blocks, out);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                             float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream) {
+  SAM_REQUIRE(p && g && m && v && seg_end && seg_lr, "sam_adam_step: null pointer");
+  SAM_REQUIRE(n > 0 && n % 4 == 0 && nseg >= 1 && nseg <= 8 && step >= 1, "sam_adam_step: need n %% 4 == 0, 1..8 segments, step >= 1");
+  AdamSegs segs = {};
+  segs.n = nseg;
+  for (int s = 0; s < nseg; ++s) {
+    SAM_REQUIRE(seg_end[s] % 4 == 0 && (s == 0 || seg_end[s] >= seg_end[s - 1]), "sam_adam_step: segment ends must be ascending multiples of 4");
+    segs.end[s] = seg_end[s]; segs.lr[s] = seg_lr[s];
+  }
+  SAM_REQUIRE(seg_end[nseg - 1] == n, "sam_adam_step: last segment must end at n");
+  const float bc1 = 1.0f - powf(beta1, (float)step);
+  const float bc2 = 1.0f - powf(beta2, (float)step);
+  const int blocks = (int)min((int64_t)4096, ((n >> 2) + 255) / 256);
+  adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, segs, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), gnorm_sq, max_norm);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  SAM_REQUIRE(x && y && n > 0 && n % 4 == 0, "sam_cast_f32_to_bf16: need n %% 4 == 0");
+  const int blocks = (int)min((int64_t)4096, ((n >> 2) + 255) / 256);
+  cast_bf16_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(x, (bf16_t*)y, n >> 2);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}

@@ -128,3 +128,104 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
     capi.call("sam_gemm_bf16", d, capi.stream_handle())
     return out
+
+
+# ----------------------------------------------------------------------------- scratch
+_WS = {}
+
+
+def _workspace(nbytes, device, tag):
+    """per-(device, tag) scratch that only grows; the kernels that use it are stream-ordered"""
+    key = (device, tag)
+    buf = _WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WS[key] = buf
+    return buf
+
+
+# ----------------------------------------------------------------------------- layernorm / reductions
+def layernorm_fwd(x, gamma, beta, eps):
+    """x [M,D] bf16 or fp32 (last dim contiguous) -> (y bf16 [M,D], mean f32 [M], rstd f32 [M])"""
+    if x.dim() != 2 or x.stride(1) != 1 or x.dtype not in (BF16, torch.float32) or not x.is_cuda:
+        raise capi.SamHipError("layernorm_fwd: need a 2-D bf16/fp32 GPU tensor with contiguous rows")
+    m, d = x.shape
+    y = torch.empty((m, d), dtype=BF16, device=x.device)
+    mean = torch.empty(m, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(m, dtype=torch.float32, device=x.device)
+    capi.call("sam_layernorm_fwd", capi.ptr(x), int(x.dtype == torch.float32), x.stride(0), capi.ptr(gamma), capi.ptr(beta), float(eps), m, d,
+              capi.ptr(y), y.stride(0), capi.ptr(mean), capi.ptr(rstd), capi.stream_handle())
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_dropped=False, p_drop=0.0, seed=0, offset=0, accumulate=True):
+    """-> (dx bf16, dx_dropped bf16 or None); dgamma/dbeta/dbias (fp32 [D]) are accumulated in place"""
+    _chk(dy, BF16, "dy")
+    m, d = x.shape
+    dx = torch.empty((m, d), dtype=BF16, device=x.device)
+    dxd = torch.empty((m, d), dtype=BF16, device=x.device) if (want_dropped and p_drop > 0) else None
+    ws = _workspace(capi.call("sam_layernorm_bwd_ws_bytes", d), x.device, "ln")
+    capi.call("sam_layernorm_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(x), int(x.dtype == torch.float32), x.stride(0), capi.ptr(mean), capi.ptr(rstd),
+              capi.ptr(gamma), m, d, capi.ptr(dx), capi.ptr(dxd), dx.stride(0), float(p_drop), int(seed), int(offset), capi.ptr(dgamma), capi.ptr(dbeta),
+              capi.ptr(dbias), int(accumulate), capi.ptr(ws), capi.stream_handle())
+    return dx, (dxd if dxd is not None else (dx if want_dropped else None))
+
+
+def colsum(x, out, accumulate=True):
+    """out[n] (+)= sum_m x[m,n]  (x bf16 [M,N], out fp32 [N])"""
+    m, n = x.shape
+    ws = _workspace(capi.call("sam_colsum_ws_bytes", n), x.device, "colsum")
+    capi.call("sam_colsum_bf16", capi.ptr(x), x.stride(0), m, n, capi.ptr(out), int(accumulate), capi.ptr(ws), capi.stream_handle())
+    return out
+
+
+# ----------------------------------------------------------------------------- loss / pointer net / optimizer
+def bce_loss(fixed, ocr, targets, loss_mask, grad_scale=1.0):
+    """fixed f32 [R,V], ocr f32 [R,No], targets f32 [R,V+No], loss_mask f32 [R] -> (loss f32 [1], d_fixed bf16 [R,V], d_ocr f32 [R,No])"""
+    r, v = fixed.shape
+    no = ocr.shape[1]
+    loss = torch.empty(1, dtype=torch.float32, device=fixed.device)
+    d_fixed = torch.empty((r, v), dtype=BF16, device=fixed.device)
+    d_ocr = torch.empty((r, no), dtype=torch.float32, device=fixed.device)
+    capi.call("sam_bce_loss", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), capi.ptr(targets), targets.stride(0), capi.ptr(loss_mask),
+              r, v, no, float(grad_scale), capi.ptr(loss), capi.ptr(d_fixed), d_fixed.stride(0), capi.ptr(d_ocr), d_ocr.stride(0), capi.stream_handle())
+    return loss, d_fixed, d_ocr
+
+
+def ptr_scores_fwd(q, k, ocr_mask_u8, scale):
+    """q bf16 [B,S,D], k bf16 [B,No,D], mask u8 [B,No] -> f32 [B,S,No]"""
+    b, s, d = q.shape
+    no = k.shape[1]
+    out = torch.empty((b, s, no), dtype=torch.float32, device=q.device)
+    capi.call("sam_ptr_scores_fwd", capi.ptr(q), capi.ptr(k), capi.ptr(ocr_mask_u8), b, s, no, d, float(scale), capi.ptr(out), out.stride(0), out.stride(1),
+              capi.stream_handle())
+    return out
+
+
+def ptr_scores_bwd(dscores, q, k, scale):
+    b, s, d = q.shape
+    no = k.shape[1]
+    dq, dk = torch.empty_like(q), torch.empty_like(k)
+    capi.call("sam_ptr_scores_bwd", capi.ptr(dscores), dscores.stride(0), dscores.stride(1), capi.ptr(q), capi.ptr(k), b, s, no, d, float(scale),
+              capi.ptr(dq), capi.ptr(dk), capi.stream_handle())
+    return dq, dk
+
+
+def sumsq(g, out):
+    ws = _workspace(capi.call("sam_sumsq_ws_bytes"), g.device, "sumsq")
+    capi.call("sam_sumsq_f32", capi.ptr(g), g.numel(), capi.ptr(out), capi.ptr(ws), capi.stream_handle())
+    return out
+
+
+def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
+    import ctypes as C
+    n = len(seg_end)
+    ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
+    lrs = (C.c_float * n)(*[float(l) for l in seg_lr])
+    capi.call("sam_adam_step", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, lrs, n, float(betas[0]), float(betas[1]),
+              float(eps), int(step), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
+
+
+def cast_bf16(x, y):
+    capi.call("sam_cast_f32_to_bf16", capi.ptr(x), capi.ptr(y), x.numel(), capi.stream_handle())
+    return y

@@ -1,0 +1,155 @@
+"""GPU parity: layernorm fwd/bwd (+ fused dropout-masked gradient and bias/gain reductions), colsum, masked BCE
+loss, pointer-net scores, gradient-norm + Adam — each against the oracle / torch fp32 on the same inputs."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sa_m4c_oracle as O
+from tests import oracle_cases as OC
+from tests.golden import common as C
+from tests.util import assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from sam_textvqa_amd import _capi, ops
+    return ops, _capi
+
+
+def rnd(shape, seed, scale=1.0, dtype=torch.bfloat16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+def test_layernorm_golden_primitives():
+    """the reference's own BertLayerNorm numbers (tests/golden/primitives.npz), D=96 fp32 input"""
+    ops, _ = _mods()
+    g = OC.load("primitives")
+    x = torch.from_numpy(C.det_uniform("prim.x", (7, 96), -4, 4))
+    w = torch.from_numpy(C.det_param("prim.LayerNorm.weight", (96,), 0.1))
+    b = torch.from_numpy(C.det_param("prim.LayerNorm.bias", (96,), 0.1))
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-12)
+    assert_close_bf16(y, torch.from_numpy(g["ln_out"]), name="LN golden fwd")
+    gy = torch.from_numpy(C.det_uniform("prim.gy", (7, 96))).to(torch.bfloat16)
+    dg, db = torch.zeros(96, device="cuda"), torch.zeros(96, device="cuda")
+    dx, _ = ops.layernorm_bwd(gy.cuda(), x.cuda(), mean, rstd, w.cuda(), dg, db)
+    # golden used the fp32 gy; ours is bf16-rounded -> compare against the oracle on the rounded gy as well
+    xo = x.clone().requires_grad_(True)
+    ln = O.BertLayerNorm(96); ln.weight.data.copy_(w); ln.bias.data.copy_(b)
+    (ln(xo) * gy.float()).sum().backward()
+    assert_close_bf16(dx, xo.grad, name="LN dx")
+    assert_close_bf16(dg, ln.weight.grad, ulps=0, name="LN dgamma"); assert_close_bf16(db, ln.bias.grad, ulps=0, name="LN dbeta")
+    assert_close_bf16(dx, torch.from_numpy(g["ln_dx"]), frac=6e-3, name="LN dx vs golden (bf16 gy)")
+
+
+@pytest.mark.parametrize("M,D,in_dtype", [(1000, 768, torch.bfloat16), (37, 768, torch.float32), (5, 3072, torch.bfloat16), (130, 256, torch.bfloat16)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_layernorm_fwd_bwd(M, D, in_dtype, p_drop):
+    ops, capi = _mods()
+    if D > 2048:
+        with pytest.raises(capi.SamHipError):
+            ops.layernorm_fwd(rnd((M, D), 1).cuda(), torch.ones(D).cuda(), torch.zeros(D).cuda(), 1e-12)
+        return
+    x = rnd((M, D), 1, 2.0, in_dtype)
+    w = 1 + 0.1 * rnd((D,), 2, dtype=torch.float32); b = 0.1 * rnd((D,), 3, dtype=torch.float32)
+    dy = rnd((M, D), 4)
+    ln = O.BertLayerNorm(D); ln.weight.data.copy_(w); ln.bias.data.copy_(b)
+    xo = x.float().requires_grad_(True)
+    yo = ln(xo); (yo * dy.float()).sum().backward()
+    y, mean, rstd = ops.layernorm_fwd(x.cuda(), w.cuda(), b.cuda(), 1e-12)
+    assert_close_bf16(y, yo, name="LN fwd")
+    dg, db, dbias = (torch.zeros(D, device="cuda") for _ in range(3))
+    dx, dxd = ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, w.cuda(), dg, db, dbias, want_dropped=True, p_drop=p_drop, seed=5, offset=9)
+    assert_close_bf16(dx, xo.grad, name="LN dx")
+    assert_close_bf16(dg, ln.weight.grad, ulps=0, name="dgamma"); assert_close_bf16(db, ln.bias.grad, ulps=0, name="dbeta")
+    if p_drop == 0:
+        assert dxd.data_ptr() == dx.data_ptr()
+        assert_close_bf16(dbias, xo.grad.sum(0), ulps=0, frac=2e-3, name="dbias")
+    else:
+        # the dropped copy must use exactly the mask of the forward GEMM epilogue with the same (seed, offset)
+        ones = torch.ones(M, 8, dtype=torch.bfloat16)
+        wsel = torch.zeros(D, 8, dtype=torch.bfloat16); wsel[:, 0] = 1       # acc = 1 everywhere
+        z = ops.gemm(ones.cuda(), wsel.cuda(), epilogue=capi.EPI_BIAS_DROPOUT_RES, p_drop=p_drop, seed=5, offset=9).float().cpu()
+        keep = z > 0
+        inv = 1.0 / (1.0 - round(p_drop * 65536) / 65536.0)
+        assert abs(keep.float().mean().item() - (1 - p_drop)) < 0.02
+        ref_dxd = torch.where(keep, xo.grad * inv, torch.zeros(()))
+        assert_close_bf16(dxd, ref_dxd, name="dropped dx")
+        assert_close_bf16(dbias, ref_dxd.sum(0), ulps=0, frac=2e-3, name="dbias (dropped)")
+    # accumulate semantics
+    dg2 = dg.clone()
+    ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, w.cuda(), dg2, db.clone())
+    assert torch.allclose(dg2, 2 * dg, rtol=1e-5, atol=1e-5)
+
+
+def test_colsum():
+    ops, _ = _mods()
+    x = rnd((1000, 2304), 7)
+    out = torch.zeros(2304, device="cuda")
+    ops.colsum(x.cuda()[:, :768], out[:768])
+    assert_close_bf16(out[:768], x[:, :768].float().sum(0), ulps=0, name="colsum view")
+    ops.colsum(x.cuda(), out, accumulate=False)
+    assert_close_bf16(out, x.float().sum(0), ulps=0, name="colsum")
+
+
+def test_bce_loss_matches_reference_loss():
+    ops, _ = _mods()
+    R, V, No = 36, 5000, 50
+    fixed, ocr = rnd((R, V), 8, 3.0, torch.float32), rnd((R, No), 9, 3.0, torch.float32)
+    ocr[:, 40:] = -10000.0                                          # padded OCR columns carry the literal -10000
+    t = (torch.rand(R, V + No, generator=torch.Generator().manual_seed(10)) > 0.98).float()
+    mask = (torch.arange(R) % 12 < 5).float()
+    s = torch.cat([fixed, ocr], 1).view(3, 12, V + No).requires_grad_(True)
+    ref = O.m4c_decoding_bce_with_mask_loss(s, t.view(3, 12, -1), mask.view(3, 12))
+    ref.backward()
+    loss, dfix, docr = ops.bce_loss(fixed.cuda(), ocr.cuda(), t.cuda(), mask.cuda(), grad_scale=0.5)
+    assert abs(loss.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    g = s.grad.view(R, -1) * 0.5
+    assert_close_bf16(dfix, g[:, :V], name="d fixed"); assert_close_bf16(docr, g[:, V:], ulps=0, name="d ocr")
+    # all-zero mask: count clamps to 1, loss 0, grads 0 (task_utils.py:28)
+    loss0, d0, _ = ops.bce_loss(fixed.cuda(), ocr.cuda(), t.cuda(), torch.zeros(R).cuda())
+    assert loss0.item() == 0.0 and (d0 == 0).all()
+
+
+def test_ptr_scores_golden_shapes():
+    ops, _ = _mods()
+    B, S, No, D = 3, 12, 50, 768
+    q, k = rnd((B, S, D), 11), rnd((B, No, D), 12)
+    mask = torch.from_numpy(C.pad_mask([50, 0, 17], No))
+    scale = 1.0 / math.sqrt(D)
+    qo, ko = q.float().requires_grad_(True), k.float().requires_grad_(True)
+    ref = qo @ ko.transpose(-1, -2) * scale + ((1.0 - mask.float()) * -10000.0).unsqueeze(1)     # sa_m4c.py:891-893
+    out = ops.ptr_scores_fwd(q.cuda(), k.cuda(), mask.to(torch.uint8).cuda(), scale)
+    assert_close_bf16(out, ref, ulps=0, frac=1e-6, name="ptr scores")
+    assert (out.cpu()[1] < -9000).all()                       # fully padded sample: every column carries -10000
+    ds = rnd((B, S, No), 13, dtype=torch.float32)
+    (ref * ds).sum().backward()
+    dq, dk = ops.ptr_scores_bwd(ds.cuda(), q.cuda(), k.cuda(), scale)
+    assert_close_bf16(dq, qo.grad, name="ptr dq"); assert_close_bf16(dk, ko.grad, name="ptr dk")
+
+
+def test_gradnorm_and_adam_match_torch():
+    ops, _ = _mods()
+    n1, n2 = 1000, 3000                   # two param groups with different lr
+    g = torch.Generator().manual_seed(14)
+    p0 = torch.randn(n1 + n2, generator=g)
+    ref_p = [p0[:n1].clone().requires_grad_(True), p0[n1:].clone().requires_grad_(True)]
+    opt = torch.optim.Adam([{"params": [ref_p[0]]}, {"params": [ref_p[1]], "lr": 3e-4}], lr=1e-3)
+    p, m, v = p0.clone().cuda(), torch.zeros(n1 + n2).cuda(), torch.zeros(n1 + n2).cuda()
+    pb = torch.empty(n1 + n2, dtype=torch.bfloat16, device="cuda")
+    nsq = torch.zeros(1, device="cuda")
+    for step in range(1, 4):
+        grad = torch.randn(n1 + n2, generator=g) * (10.0 if step == 2 else 0.01)
+        ref_p[0].grad, ref_p[1].grad = grad[:n1].clone(), grad[n1:].clone()
+        total = torch.nn.utils.clip_grad_norm_(ref_p, 0.25)
+        opt.step()
+        gd = grad.cuda()
+        ops.sumsq(gd, nsq)
+        assert abs(math.sqrt(nsq.item()) - total.item()) <= 1e-5 * total.item()
+        ops.adam_step(p, gd, m, v, pb, [n1, n1 + n2], [1e-3, 3e-4], step, gnorm_sq=nsq, max_norm=0.25)
+        ref = torch.cat([ref_p[0].detach(), ref_p[1].detach()])
+        assert torch.allclose(p.cpu(), ref, rtol=1e-5, atol=1e-6), (p.cpu() - ref).abs().max()
+        assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
