@@ -1,0 +1,245 @@
+"""torch.autograd.Function wrappers chaining the C-ABI kernels.
+
+Parameter gradients are NOT returned to autograd: wgrad GEMMs and the fused reductions accumulate straight into the
+flat gradient buffer (params.py).  Each Function receives one parameter tensor as an `anchor` input only so that its
+output requires grad even when the activation input does not."""
+import math
+
+import torch
+from torch.autograd import Function
+
+from . import _capi as capi
+from . import ops
+from .params import FlatParams, flat_of
+
+BF16 = torch.bfloat16
+
+
+class DropoutClock:
+    """Philox (seed, offset) source: every dropout site of every step gets a fresh offset; forward and backward of
+    one site share it.  Seed is per rank so data-parallel replicas draw different masks."""
+
+    def __init__(self):
+        self.seed = 0x5A4D3443  # "SAM4C"
+        self.offset = 0
+
+    def manual_seed(self, seed):
+        self.seed, self.offset = int(seed) & 0xFFFFFFFFFFFFFFFF, 0
+
+    def next(self):
+        self.offset += 1
+        return self.seed, self.offset
+
+
+dropout_clock = DropoutClock()
+
+
+def _w(p):
+    """bf16 shadow of a prepared parameter"""
+    s = getattr(p, "_sam_bf16", None)
+    if s is None:
+        flat_of(p)
+    return s
+
+
+def _fused_qkv(att):
+    """(wqkv bf16 [3D,D], bqkv f32 [3D], dwqkv f32 [3D,D], dbqkv f32 [3D]) as single views over q|k|v"""
+    cache = getattr(att, "_sam_qkv", None)
+    if cache is None:
+        ws = [att.query.weight, att.key.weight, att.value.weight]
+        bs = [att.query.bias, att.key.bias, att.value.bias]
+        views = (FlatParams.adjacent(ws, "_sam_bf16"), FlatParams.adjacent(bs, None), FlatParams.adjacent(ws, "grad"), FlatParams.adjacent(bs, "grad"))
+        if any(v is None for v in views):
+            raise RuntimeError("query/key/value parameters are not adjacent in flat storage; prepare() the enclosing module")
+        cache = att._sam_qkv = views
+    return cache
+
+
+# ------------------------------------------------------------------------------------------------ linear
+class LinearFn(Function):
+    """y = x W^T + b  (nn.Linear sites outside the encoder layers: input projections, classifier, pointer q/k)"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, out_f32):
+        ctx.weight, ctx.bias = weight, bias
+        x2 = x.reshape(-1, x.shape[-1])
+        w = _w(weight)
+        k_pad = w.stride(0) if w.stride(0) != w.shape[1] else w.shape[1]
+        if x2.shape[1] != w.shape[1]:
+            raise capi.SamHipError("LinearFn: input width %d != in_features %d" % (x2.shape[1], w.shape[1]))
+        if k_pad != x2.shape[1] or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.dtype != BF16:
+            xp = torch.zeros((x2.shape[0], k_pad), dtype=BF16, device=x.device)   # zero-padded K (e.g. 3002 -> 3008, 4 -> 8)
+            xp[:, : x2.shape[1]] = x2
+            x2 = xp
+        wfull = torch.as_strided(w, (w.shape[0], k_pad), (w.stride(0), 1))
+        y = ops.gemm(x2, wfull, epilogue=capi.EPI_BIAS, bias=bias, out_dtype=torch.float32 if out_f32 else BF16)
+        ctx.save_for_backward(x2)
+        ctx.in_shape, ctx.in_dtype, ctx.k_pad = x.shape, x.dtype, k_pad
+        return y.view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        n = weight.shape[0]
+        dy2 = dy.reshape(-1, n)
+        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8:
+            dy2 = dy2.to(BF16).contiguous()
+        w = _w(weight)
+        wfull = torch.as_strided(w, (n, ctx.k_pad), (w.stride(0), 1))
+        g = weight.grad
+        gfull = torch.as_strided(g, (n, ctx.k_pad), (g.stride(0), 1))
+        ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gfull, accumulate=True)      # dW += dy^T x
+        if bias is not None:
+            ops.colsum(dy2, bias.grad, accumulate=True)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, wfull, b_kcontig=False)[:, : ctx.in_shape[-1]]               # dx = dy W
+            dx = dx.reshape(ctx.in_shape).to(ctx.in_dtype)
+        return dx, None, None, None
+
+
+def linear(x, lin, out_f32=False):
+    return LinearFn.apply(x, lin.weight, lin.bias, out_f32)
+
+
+# ------------------------------------------------------------------------------------------------ layernorm
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype not in (BF16, torch.float32) or x2.stride(1) != 1 or x2.stride(0) % 4:
+            x2 = x2.contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.weight, ctx.bias, ctx.in_shape, ctx.in_dtype = weight, bias, x.shape, x.dtype
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16 or not dy2.is_contiguous():
+            dy2 = dy2.to(BF16).contiguous()
+        dx, _ = ops.layernorm_bwd(dy2, x2, mean, rstd, ctx.weight, ctx.weight.grad, ctx.bias.grad)
+        return (dx.view(ctx.in_shape).to(ctx.in_dtype) if ctx.needs_input_grad[0] else None), None, None, None
+
+
+def layer_norm(x, ln):
+    return LayerNormFn.apply(x, ln.weight, ln.bias, ln.variance_epsilon)
+
+
+# ------------------------------------------------------------------------------------------------ encoder layer
+class EncoderLayerFn(Function):
+    """One BERT-style encoder layer (spatial or plain — the difference is entirely in `allow`), forward and backward,
+    13 kernel launches forward / 21 backward, nothing but these kernels touches the activations.
+    Reference: SpatialBertLayer.forward sam/sa_m4c.py:670-684 (and pytorch-transformers BertLayer for 'n' layers)."""
+
+    @staticmethod
+    def forward(ctx, x, anchor, layer, allow, batch, p_attn, p_hid):
+        att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        wqkv, bqkv, _, _ = _fused_qkv(att)
+        heads = att.num_attention_heads
+        scale = 1.0 / math.sqrt(att.attention_head_size)
+        seeds = [dropout_clock.next() for _ in range(3)]
+        qkv = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
+        ctxv, lse2, keep = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0])
+        z1 = ops.gemm(ctxv, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x, p_drop=p_hid,
+                      seed=seeds[1][0], offset=seeds[1][1])
+        a, mean1, rstd1 = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
+        pre = torch.empty((x.shape[0], inter.dense.weight.shape[0]), dtype=BF16, device=x.device)
+        h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU, bias=inter.dense.bias, aux_out=pre)
+        z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a, p_drop=p_hid,
+                      seed=seeds[2][0], offset=seeds[2][1])
+        y, mean2, rstd2 = ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)
+        ctx.save_for_backward(x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow)
+        ctx.layer, ctx.batch, ctx.p_attn, ctx.p_hid, ctx.seeds, ctx.scale = layer, batch, p_attn, p_hid, seeds, scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
+        layer, p_hid, seeds = ctx.layer, ctx.p_hid, ctx.seeds
+        att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        wqkv, _, dwqkv, dbqkv = _fused_qkv(att)
+        if dy.dtype != BF16 or not dy.is_contiguous():
+            dy = dy.to(BF16).contiguous()
+        # ---- output block: y = LN(dropout(h W2^T + b2) + a)
+        dz2, dy2 = ops.layernorm_bwd(dy, z2, mean2, rstd2, out.LayerNorm.weight, out.LayerNorm.weight.grad, out.LayerNorm.bias.grad,
+                                     dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1])
+        ops.gemm(dy2, h, a_kcontig=False, b_kcontig=False, out=out.dense.weight.grad, accumulate=True)
+        dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre)
+        # ---- intermediate: h = gelu(a W1^T + b1)
+        ops.colsum(dpre, inter.dense.bias.grad, accumulate=True)
+        ops.gemm(dpre, a, a_kcontig=False, b_kcontig=False, out=inter.dense.weight.grad, accumulate=True)
+        da = ops.gemm(dpre, _w(inter.dense.weight), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz2)   # + residual path
+        # ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
+        dz1, dy1 = ops.layernorm_bwd(da, z1, mean1, rstd1, so.LayerNorm.weight, so.LayerNorm.weight.grad, so.LayerNorm.bias.grad,
+                                     dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1])
+        ops.gemm(dy1, ctxv, a_kcontig=False, b_kcontig=False, out=so.dense.weight.grad, accumulate=True)
+        dctx = ops.gemm(dy1, _w(so.dense.weight), b_kcontig=False)
+        # ---- attention core + fused QKV projection
+        dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn)
+        ops.colsum(dqkv, dbqkv, accumulate=True)
+        ops.gemm(dqkv, x, a_kcontig=False, b_kcontig=False, out=dwqkv, accumulate=True)
+        dx = ops.gemm(dqkv, wqkv, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz1) if ctx.needs_input_grad[0] else None
+        return dx, None, None, None, None, None, None
+
+
+def encoder_layer(x2d, layer, allow, batch, training):
+    cfg_p_attn = layer.attention.self.dropout_p if training else 0.0
+    cfg_p_hid = layer.output.dropout_p if training else 0.0
+    return EncoderLayerFn.apply(x2d, layer.output.LayerNorm.weight, layer, allow, batch, cfg_p_attn, cfg_p_hid)
+
+
+class AttentionFn(Function):
+    """stand-alone fused attention (module-level SpatialBertSelfAttention / BertSelfAttention API)"""
+
+    @staticmethod
+    def forward(ctx, qkv, allow, batch, heads, scale, p_drop):
+        qkv = qkv.contiguous()
+        seed = dropout_clock.next()
+        out, lse2, keep = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed)
+        ctx.save_for_backward(qkv, lse2, keep, allow)
+        ctx.cfg = (batch, heads, scale, p_drop)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, lse2, keep, allow = ctx.saved_tensors
+        batch, heads, scale, p_drop = ctx.cfg
+        return ops.attn_bwd(dout.to(BF16).contiguous(), qkv, lse2, allow, keep, batch, heads, scale, p_drop), None, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------ pointer net / loss
+class PtrScoresFn(Function):
+    @staticmethod
+    def forward(ctx, q, k, ocr_mask_u8, scale):
+        q, k = q.contiguous(), k.contiguous()
+        ctx.save_for_backward(q, k)
+        ctx.scale = scale
+        return ops.ptr_scores_fwd(q, k, ocr_mask_u8, scale)
+
+    @staticmethod
+    def backward(ctx, ds):
+        q, k = ctx.saved_tensors
+        dq, dk = ops.ptr_scores_bwd(ds.float().contiguous(), q, k, ctx.scale)
+        return dq, dk, None, None
+
+
+class BceLossFn(Function):
+    """M4CDecodingBCEWithMaskLoss (sam/task_utils.py:19-30) on the two score blocks; gradient computed in the forward pass"""
+
+    @staticmethod
+    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale):
+        r = fixed.shape[0] * fixed.shape[1]
+        f2, o2 = fixed.reshape(r, -1), ocr.reshape(r, -1)
+        loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale)
+        ctx.save_for_backward(d_fixed, d_ocr)
+        ctx.shapes = (fixed.shape, ocr.shape)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d_fixed, d_ocr = ctx.saved_tensors   # upstream g is 1 for a scalar loss .backward(); honour it anyway
+        return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None

@@ -1,0 +1,558 @@
+"""Host-side mirror of the reference's nn.Module surface for the SA-M4C hot path (sam/sa_m4c.py).
+
+Same class names, constructor arguments, config keys, forward signatures, batch_dict side effects and state_dict
+keys as the reference, so a reference checkpoint loads unchanged and callers (train.py:92-94,133;
+task_utils.py:118; evaluator.py:168) can switch imports.  All arithmetic runs in the HIP kernels of
+libsam_hip.so through autograd.py; there is no eager fallback: the modules raise if the library is missing or
+the tensors are not on the GPU.  Activations are bf16 between kernels, parameters are fp32 masters with bf16
+shadows (params.py)."""
+import math
+from collections import Counter
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import ops
+from .autograd import (BF16, AttentionFn, PtrScoresFn, encoder_layer, layer_norm, linear)
+from .params import prepare
+from .registry import registry
+
+
+class BertConfig:
+    """pytorch-transformers BertConfig defaults; from_dict copies EVERY key into the object (train.py:92-93)."""
+
+    DEFAULTS = dict(vocab_size=30522, hidden_size=768, num_hidden_layers=12, num_attention_heads=12, intermediate_size=3072,
+                    hidden_act="gelu", hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1, max_position_embeddings=512,
+                    type_vocab_size=2, initializer_range=0.02, layer_norm_eps=1e-12, output_attentions=False, output_hidden_states=False)
+
+    def __init__(self, **kw):
+        self.__dict__.update(self.DEFAULTS)
+        self.__dict__.update(kw)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**dict(d))
+
+
+# ------------------------------------------------------------------------------------------ mask plumbing
+class AllowBits:
+    """Per-batch allow-bit masks: `base` [B,1,N,NW] (key padding + prefix-LM/causal) and a cache of the per-head
+    spatial masks derived from it, keyed by the relation tensor they were built from.  Built once per batch, shared
+    by all layers' forward and backward."""
+
+    def __init__(self, base):
+        self.base = base
+        self._spatial = {}
+
+    def spatial(self, adj, n_txt, n_heads, quadrants):
+        key = (adj.data_ptr(), adj._version, n_txt, n_heads, tuple(quadrants))
+        bits = self._spatial.get(key)
+        if bits is None:
+            if adj.dtype != torch.int8:
+                adj = adj.to(torch.int8)
+            adj = adj.to(self.base.device, non_blocking=True).contiguous()
+            bits = self._spatial[key] = ops.mask_bits_spatial(self.base, adj, n_txt, n_heads, quadrants)
+        return bits
+
+
+def as_allow(attention_mask):
+    """accept either AllowBits (internal callers) or the reference's additive [B,1,N,N] float mask (module-level API)"""
+    if isinstance(attention_mask, AllowBits):
+        return attention_mask
+    cached = getattr(attention_mask, "_sam_allow", None)
+    if cached is None or cached[0] != attention_mask._version:
+        m = attention_mask
+        if m.dim() == 4 and m.shape[2] == 1:      # TextBert-style [B,1,1,N] key mask
+            m = m.expand(-1, -1, m.shape[3], -1)
+        bits = ops.mask_bits_from_additive(m.to(device="cuda", dtype=torch.float32).contiguous())
+        cached = (attention_mask._version, AllowBits(bits))
+        try:
+            attention_mask._sam_allow = cached
+        except Exception:
+            pass
+    return cached[1]
+
+
+def _to_rows(hidden_states):
+    b, n, d = hidden_states.shape
+    x = hidden_states.reshape(b * n, d)
+    if x.dtype != BF16 or not x.is_contiguous():
+        x = x.to(BF16).contiguous()
+    return x, b, n
+
+
+def _check_head_mask(head_mask):
+    if head_mask is not None and any(h is not None for h in (head_mask if isinstance(head_mask, (list, tuple)) else [head_mask])):
+        raise NotImplementedError("head_mask is always None on the reference path (sa_m4c.py:846); not supported by the fused kernels")
+
+
+class _HipModule(nn.Module):
+    """base: lazily moves this subtree into flat GPU storage on first use"""
+
+    def _ready(self):
+        fp = self.__dict__.get("_sam_flat_params")
+        if fp is None:
+            first = next(self.parameters(), None)
+            if first is None or getattr(first, "_sam_flat", None) is not None:
+                return                      # parameter-free, or a child of an already prepared root
+            fp = prepare(self)              # this module becomes a storage root
+        fp.ensure_fresh()                   # only roots pay for the version scan
+
+
+# ------------------------------------------------------------------------------------------ leaf blocks
+class BertLayerNorm(_HipModule):
+    """sam/sa_m4c.py:1016-1028"""
+
+    def __init__(self, hidden_size, eps=1e-12):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(hidden_size))
+        self.bias = nn.Parameter(torch.zeros(hidden_size))
+        self.variance_epsilon = eps
+
+    def forward(self, x):
+        self._ready()
+        return layer_norm(x, self)
+
+
+class BertSelfOutput(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.hidden_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_p = config.hidden_dropout_prob
+
+    def forward(self, hidden_states, input_tensor):
+        self._ready()
+        h = F.dropout(linear(hidden_states.to(BF16), self.dense), self.dropout_p, self.training)
+        return layer_norm(h + input_tensor.to(BF16), self.LayerNorm)
+
+
+class BertIntermediate(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_act not in ("gelu",):
+            raise NotImplementedError("only erf-GELU (hidden_act='gelu') is implemented, as used by every shipped config")
+        self.dense = nn.Linear(config.hidden_size, config.intermediate_size)
+
+    def forward(self, hidden_states):
+        self._ready()
+        return F.gelu(linear(hidden_states.to(BF16), self.dense))
+
+
+class BertOutput(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.dense = nn.Linear(config.intermediate_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_p = config.hidden_dropout_prob
+
+    forward = BertSelfOutput.forward
+
+
+class BertSelfAttention(_HipModule):
+    """plain additive-mask MHA of the 'n' layers / TextBert (pytorch-transformers BertSelfAttention)"""
+
+    def __init__(self, config):
+        super().__init__()
+        if config.hidden_size % config.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, config.num_attention_heads))
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = config.hidden_size // config.num_attention_heads
+        self.all_head_size = config.hidden_size
+        self.output_attentions = config.output_attentions
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout_p = config.attention_probs_dropout_prob
+
+    def _allow_bits(self, attention_mask, spatial_adj_matrix=None):
+        return as_allow(attention_mask).base
+
+    def forward(self, hidden_states, attention_mask, head_mask=None):
+        return self._attend(hidden_states, self._allow_bits(attention_mask), head_mask)
+
+    def _attend(self, hidden_states, allow, head_mask):
+        self._ready()
+        _check_head_mask(head_mask)
+        if self.output_attentions:
+            raise NotImplementedError("output_attentions: the fused kernel never materialises the probabilities")
+        x, b, n = _to_rows(hidden_states)
+        qkv = torch.cat([linear(x, self.query), linear(x, self.key), linear(x, self.value)], dim=1)
+        p = self.dropout_p if self.training else 0.0
+        ctx = AttentionFn.apply(qkv, allow, b, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size), p)
+        return (ctx.view(b, n, -1).to(hidden_states.dtype),)
+
+
+class SpatialBertSelfAttention(BertSelfAttention):
+    """sam/sa_m4c.py:399-610: one head per spatial relation; mask = min(attention_mask, relation mask), dead rows -> 0"""
+
+    def __init__(self, config, use_implicit=False):
+        assert hasattr(config, "num_spatial_relations")
+        nn.Module.__init__(self)
+        self.num_attention_heads = config.num_spatial_relations
+        self.num_spatial_relations = config.num_spatial_relations
+        if hasattr(config, "num_implicit_relations") and use_implicit:
+            self.num_attention_heads += config.num_implicit_relations
+            self.num_implicit_relations = config.num_implicit_relations
+        if config.hidden_size % self.num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (config.hidden_size, self.num_attention_heads))
+        self.output_attentions = config.output_attentions
+        self.max_seq_len = config.max_seq_length
+        self.mask_quadrants = list(config.attention_mask_quadrants)
+        self.max_decoding_steps = config.num_decoding_steps
+        self.attention_head_size = config.hidden_size // self.num_attention_heads
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self.query = nn.Linear(config.hidden_size, self.all_head_size)
+        self.key = nn.Linear(config.hidden_size, self.all_head_size)
+        self.value = nn.Linear(config.hidden_size, self.all_head_size)
+        self.dropout_p = 0.0 if getattr(config, "no_drop", False) else config.attention_probs_dropout_prob
+        self.use_bias = bool(getattr(config, "use_bias", False))
+        if self.use_bias:
+            raise NotImplementedError("use_bias head biases (sa_m4c.py:439-443) are off in every shipped config; not implemented")
+
+    def _allow_bits(self, attention_mask, spatial_adj_matrix=None):
+        return as_allow(attention_mask).spatial(spatial_adj_matrix, self.max_seq_len, self.num_attention_heads, self.mask_quadrants)
+
+    def forward(self, hidden_states, attention_mask, spatial_adj_matrix, head_mask=None):
+        return self._attend(hidden_states, self._allow_bits(attention_mask, spatial_adj_matrix), head_mask)
+
+
+class BertAttention(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.self = BertSelfAttention(config)
+        self.output = BertSelfOutput(config)
+
+    def forward(self, input_tensor, attention_mask, head_mask=None):
+        so = self.self(input_tensor, attention_mask, head_mask)
+        return (self.output(so[0], input_tensor),) + so[1:]
+
+
+class SpatialBertAttention(_HipModule):
+    """sam/sa_m4c.py:613-657 (prune_heads omitted: it references an undefined symbol upstream and is never called)"""
+
+    def __init__(self, config, use_implicit=False):
+        super().__init__()
+        self.self = SpatialBertSelfAttention(config, use_implicit)
+        self.output = BertSelfOutput(config)
+        self.pruned_heads = set()
+
+    def forward(self, input_tensor, attention_mask, spatial_adj_matrix, head_mask=None):
+        so = self.self(input_tensor, attention_mask, spatial_adj_matrix, head_mask)
+        return (self.output(so[0], input_tensor),) + so[1:]
+
+
+class _FusedLayer(_HipModule):
+    def _run(self, hidden_states, allow, head_mask):
+        self._ready()
+        _check_head_mask(head_mask)
+        if self.attention.self.output_attentions:
+            raise NotImplementedError("output_attentions is not available on the fused path")
+        x, b, n = _to_rows(hidden_states)
+        y = encoder_layer(x, self, allow, b, self.training)
+        return (y.view(b, n, -1).to(hidden_states.dtype),)
+
+
+class BertLayer(_FusedLayer):
+    """pytorch-transformers BertLayer ('n' layers, sa_m4c.py:718-722,741-743; TextBert layers)"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.attention = BertAttention(config)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask, head_mask=None):
+        return self._run(hidden_states, self.attention.self._allow_bits(attention_mask), head_mask)
+
+
+class SpatialBertLayer(_FusedLayer):
+    """sam/sa_m4c.py:660-684"""
+
+    def __init__(self, config, use_implicit=False):
+        super().__init__()
+        self.attention = SpatialBertAttention(config, use_implicit)
+        self.intermediate = BertIntermediate(config)
+        self.output = BertOutput(config)
+
+    def forward(self, hidden_states, attention_mask, spatial_adj_matrix, head_mask=None):
+        return self._run(hidden_states, self.attention.self._allow_bits(attention_mask, spatial_adj_matrix), head_mask)
+
+
+class BertEncoder(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.layer = nn.ModuleList([BertLayer(config) for _ in range(config.num_hidden_layers)])
+
+    def forward(self, hidden_states, attention_mask, head_mask=None):
+        allow = as_allow(attention_mask)
+        for i, layer in enumerate(self.layer):
+            hidden_states = layer(hidden_states, allow, None if head_mask is None else head_mask[i])[0]
+        return (hidden_states,)
+
+
+class BertEmbeddings(_HipModule):
+    def __init__(self, config):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=0)
+        self.position_embeddings = nn.Embedding(config.max_position_embeddings, config.hidden_size)
+        self.token_type_embeddings = nn.Embedding(config.type_vocab_size, config.hidden_size)
+        self.LayerNorm = BertLayerNorm(config.hidden_size, eps=config.layer_norm_eps)
+        self.dropout_p = config.hidden_dropout_prob
+
+    def forward(self, input_ids):
+        self._ready()
+        n = input_ids.size(1)
+        pos = torch.arange(n, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
+        e = self.word_embeddings(input_ids) + self.position_embeddings(pos) + self.token_type_embeddings(torch.zeros_like(input_ids))
+        return F.dropout(layer_norm(e, self.LayerNorm), self.dropout_p, self.training)
+
+
+def _bert_init_weights(module, initializer_range):
+    """BertPreTrainedModel.init_weights(): N(0, range) Linear/Embedding weights, LN = 1/0, Linear bias 0"""
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Embedding)):
+            m.weight.data.normal_(mean=0.0, std=initializer_range)
+        elif isinstance(m, BertLayerNorm):
+            m.bias.data.zero_()
+            m.weight.data.fill_(1.0)
+        if isinstance(m, nn.Linear) and m.bias is not None:
+            m.bias.data.zero_()
+
+
+class TextBert(_HipModule):
+    """sam/sa_m4c.py:374-396"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = BertEncoder(config)
+        _bert_init_weights(self, config.initializer_range)
+
+    def forward(self, batch_dict):
+        self._ready()
+        x = self.embeddings(batch_dict["question_indices"])
+        allow = AllowBits(ops.mask_bits_prefix_lm(batch_dict["question_mask"].to(torch.uint8).contiguous(), 0))
+        return self.encoder(x, allow, head_mask=[None] * self.config.num_hidden_layers)[0]
+
+
+MATRIX_TYPE_MAP = {"none": "1", "share3": "3", "share5": "5", "share7": "7", "share9": "9"}
+
+
+class BertSpatialEncoder(_HipModule):
+    """sam/sa_m4c.py:687-770"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.output_attentions = config.output_attentions
+        self.output_hidden_states = config.output_hidden_states
+        self.layer_type_list = list(config.layer_type_list)
+        cnt = Counter(self.layer_type_list)
+        self.num_spatial_layers, self.num_normal_layers, self.num_implicit_layers = cnt["s"], cnt["n"], cnt["i"]
+        mix = getattr(config, "mix_list", None)
+        self.mix_list = ["none"] * len(self.layer_type_list) if mix is None else list(mix)
+        assert len(self.mix_list) == len(self.layer_type_list)
+        self.matrix_type_map = dict(MATRIX_TYPE_MAP)
+        self.normal_layers = nn.ModuleList([BertLayer(config) for _ in range(self.num_normal_layers)])
+        self.spatial_layers = nn.ModuleList([SpatialBertLayer(config) for _ in range(self.num_spatial_layers)])
+        self.implicit_layers = nn.ModuleList([SpatialBertLayer(config, True) for _ in range(self.num_implicit_layers)])
+
+    def forward(self, hidden_states, attention_mask, batch_dict, head_mask=None):
+        allow = as_allow(attention_mask)
+        normal, spatial = iter(self.normal_layers), iter(self.spatial_layers)
+        all_hidden = ()
+        for kind, mix in zip(self.layer_type_list, self.mix_list):
+            if self.output_hidden_states:
+                all_hidden += (hidden_states,)
+            if kind == "n":
+                hidden_states = next(normal)(hidden_states, allow)[0]
+            elif kind == "s":
+                adj = batch_dict["spatial_adj_matrices"][self.matrix_type_map[mix]]
+                hidden_states = next(spatial)(hidden_states, allow, adj)[0]
+            else:
+                raise ValueError   # 'i' layers are rejected by the reference as well (sa_m4c.py:751-752)
+        assert next(normal, None) is None and next(spatial, None) is None
+        outputs = (hidden_states,)
+        if self.output_hidden_states:
+            outputs += (all_hidden + (hidden_states,),)
+        return outputs
+
+
+class PrevPredEmbeddings(_HipModule):
+    """sam/sa_m4c.py:900-948 — without materialising the [B, V+n_ocr, D] table (15.5 MB/sample upstream): the two
+    sources are gathered separately and selected."""
+
+    def __init__(self, config):
+        super().__init__()
+        h, eps = config.hidden_size, config.layer_norm_eps
+        self.position_embeddings = nn.Embedding(100, h)
+        self.token_type_embeddings = nn.Embedding(5, h)
+        self.ans_layer_norm = BertLayerNorm(h, eps=eps)
+        self.ocr_layer_norm = BertLayerNorm(h, eps=eps)
+        self.emb_layer_norm = BertLayerNorm(h, eps=eps)
+        self.dropout_p = config.hidden_dropout_prob
+
+    def forward(self, ans_emb, ocr_emb, prev_inds):
+        self._ready()
+        assert prev_inds.dim() == 2 and prev_inds.dtype == torch.long and ans_emb.dim() == 2
+        b, s = prev_inds.shape
+        n_ans, n_ocr = ans_emb.size(0), ocr_emb.size(1)
+        ans = layer_norm(ans_emb, self.ans_layer_norm)                       # [V, D] bf16
+        ocr = layer_norm(ocr_emb, self.ocr_layer_norm).reshape(b * n_ocr, -1)  # [B*n_ocr, D]
+        is_ocr = prev_inds.ge(n_ans)
+        from_ans = F.embedding(prev_inds.clamp(max=n_ans - 1), ans)
+        ocr_idx = (prev_inds - n_ans).clamp(min=0) + (torch.arange(b, device=prev_inds.device) * n_ocr).unsqueeze(-1)
+        from_ocr = F.embedding(ocr_idx, ocr)
+        raw = torch.where(is_ocr.unsqueeze(-1), from_ocr, from_ans)
+        pos = torch.arange(s, dtype=torch.long, device=prev_inds.device).unsqueeze(0).expand(b, s)
+        emb = self.position_embeddings(pos) + self.token_type_embeddings(is_ocr.long())
+        emb = F.dropout(layer_norm(emb, self.emb_layer_norm), self.dropout_p, self.training)
+        return raw + emb
+
+
+class MMT(_HipModule):
+    """sam/sa_m4c.py:773-863"""
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.prev_pred_embeddings = PrevPredEmbeddings(config)
+        self.encoder = BertSpatialEncoder(config)
+        _bert_init_weights(self, config.initializer_range)
+
+    def forward(self, batch_dict, fixed_ans_emb):
+        self._ready()
+        dec_emb = self.prev_pred_embeddings(fixed_ans_emb, batch_dict["ocr_mmt_in"], batch_dict["train_prev_inds"])
+        x = torch.cat([batch_dict["text_bert_emb"].to(BF16), batch_dict["obj_mmt_in"].to(BF16), batch_dict["ocr_mmt_in"].to(BF16),
+                       dec_emb.to(BF16)], dim=1)
+        n_txt = batch_dict["question_mask"].size(-1)
+        n_obj = batch_dict["pad_obj_mask"].size(-1)
+        n_ocr = batch_dict["pad_ocr_mask"].size(-1)
+        n_dec = dec_emb.size(1)
+        key_valid = torch.cat([batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"]], dim=1)
+        allow = AllowBits(ops.mask_bits_prefix_lm(key_valid.to(device=x.device, dtype=torch.uint8).contiguous(), n_dec))
+        seq = self.encoder(x, allow, batch_dict, head_mask=[None] * self.config.num_hidden_layers)[0]
+        ocr0 = n_txt + n_obj
+        return {"mmt_seq_output": seq, "mmt_txt_output": seq[:, :n_txt], "mmt_ocr_output": seq[:, ocr0: ocr0 + n_ocr],
+                "mmt_dec_output": seq[:, -n_dec:]}
+
+
+class OcrPtrNet(_HipModule):
+    """sam/sa_m4c.py:866-897"""
+
+    def __init__(self, hidden_size, query_key_size=None):
+        super().__init__()
+        self.hidden_size = hidden_size
+        self.query_key_size = hidden_size if query_key_size is None else query_key_size
+        self.query = nn.Linear(hidden_size, self.query_key_size)
+        self.key = nn.Linear(hidden_size, self.query_key_size)
+
+    def forward(self, query_inputs, key_inputs, attention_mask):
+        self._ready()
+        assert attention_mask.dim() == 2
+        squeeze = query_inputs.dim() == 2
+        if squeeze:
+            query_inputs = query_inputs.unsqueeze(1)
+        q = linear(query_inputs.to(BF16), self.query)
+        k = linear(key_inputs.to(BF16), self.key)
+        mask = attention_mask.to(device=q.device).ne(0).to(torch.uint8).contiguous()
+        s = PtrScoresFn.apply(q, k, mask, 1.0 / math.sqrt(self.query_key_size))
+        return s.squeeze(1) if squeeze else s
+
+
+class SAM4C(_HipModule):
+    """sam/sa_m4c.py:20-371 (aux heads, beam search and the fc7-finetune image encoder are out of scope: disabled /
+    dead upstream)."""
+
+    def __init__(self, mmt_config, text_bert_config, num_answers=None, bos_idx=None):
+        super().__init__()
+        self.mmt_config, self.text_bert_config = mmt_config, text_bert_config
+        self.normalize = mmt_config.normalize
+        if getattr(mmt_config, "use_aux_heads", False):
+            raise NotImplementedError("use_aux_heads is absent from every shipped config; not implemented")
+        self.finetune_modules = []
+        h = mmt_config.hidden_size
+        if text_bert_config.text_bert_init_from_bert_base:
+            raise NotImplementedError("text_bert_init_from_bert_base needs a network download; load a checkpoint instead")
+        self.text_bert = TextBert(text_bert_config)
+        self.text_bert_out_linear = nn.Identity() if h == 768 else nn.Linear(768, h)
+        self.linear_obj_feat_to_mmt_in = nn.Linear(mmt_config.obj_feature_size, h)
+        self.linear_obj_bbox_to_mmt_in = nn.Linear(4, h)
+        self.obj_feat_layer_norm = BertLayerNorm(h)
+        self.obj_bbox_layer_norm = BertLayerNorm(h)
+        self.obj_drop_p = mmt_config.obj_drop
+        self.linear_ocr_feat_to_mmt_in = nn.Linear(mmt_config.ocr_feature_size, h)
+        self.linear_ocr_bbox_to_mmt_in = nn.Linear(4, h)
+        self.ocr_feat_layer_norm = BertLayerNorm(h)
+        self.ocr_bbox_layer_norm = BertLayerNorm(h)
+        self.ocr_drop_p = mmt_config.ocr_drop
+        self.mmt = MMT(mmt_config)
+        self.finetune_modules.append({"module": self.mmt, "lr_scale": mmt_config.lr_scale_mmt})
+        self.ocr_ptr_net = OcrPtrNet(hidden_size=h, query_key_size=mmt_config.ptr_query_size)
+        n_out = num_answers if num_answers is not None else len(registry.answer_vocab)
+        self.bos_idx = bos_idx if bos_idx is not None else registry.BOS_IDX
+        self.classifier = nn.Linear(h, n_out)
+
+    def _forward_obj_encoding(self, bd):
+        feat = bd["pad_obj_features"]
+        if self.normalize:
+            feat = F.normalize(feat, dim=-1)
+        x = (layer_norm(linear(feat.to(BF16), self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
+             + layer_norm(linear(bd["pad_obj_bboxes"][:, :, :-1].to(BF16), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
+        bd["obj_mmt_in"] = F.dropout(x, self.obj_drop_p, self.training)
+
+    def _forward_ocr_encoding(self, bd):
+        ft, ph, fc = bd["ocr_fasttext"], bd["ocr_phoc"], bd["pad_ocr_features"]
+        assert ft.size(-1) == 300 and ph.size(-1) == 604
+        if self.normalize:
+            ft, ph, fc = F.normalize(ft, dim=-1), F.normalize(ph, dim=-1), F.normalize(fc, dim=-1)
+        order = fc.new_zeros((ph.size(0), ph.size(1), 50))                 # legacy all-zero order vectors, sa_m4c.py:242
+        parts = [ft, ph, fc, order] if self.mmt_config.use_phoc_fasttext else [fc, order]
+        feat = torch.cat([p.to(BF16) for p in parts], dim=-1)
+        x = (layer_norm(linear(feat, self.linear_ocr_feat_to_mmt_in), self.ocr_feat_layer_norm)
+             + layer_norm(linear(bd["pad_ocr_bboxes"][:, :, :-1].to(BF16), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
+        bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)
+
+    def _forward_mmt(self, bd):
+        t = self.text_bert(bd)
+        bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+        bd.update(self.mmt(bd, fixed_ans_emb=self.classifier.weight))
+
+    def _forward_output(self, bd):
+        dec = bd["mmt_dec_output"]
+        bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
+        bd["dynamic_ocr_scores"] = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
+        bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
+
+    def forward(self, batch_dict, use_beam_search=False):
+        if use_beam_search:
+            raise NotImplementedError("beam search is disabled upstream (train.py:222-225) and out of scope")
+        self._ready()
+        self._forward_obj_encoding(batch_dict)
+        self._forward_ocr_encoding(batch_dict)
+        if self.training:
+            self._forward_mmt(batch_dict)
+            self._forward_output(batch_dict)
+        else:   # greedy decoding, sa_m4c.py:285-302
+            steps = batch_dict["train_prev_inds"].size(1)
+            batch_dict["train_prev_inds"] = torch.zeros_like(batch_dict["train_prev_inds"])
+            batch_dict["train_prev_inds"][:, 0] = self.bos_idx
+            for _ in range(steps):
+                self._forward_mmt(batch_dict)
+                self._forward_output(batch_dict)
+                batch_dict["train_prev_inds"][:, 1:] = batch_dict["scores"].argmax(dim=-1)[:, :-1]
+        return {"textvqa_scores": batch_dict["scores"]}
+
+    def get_optimizer_parameters(self, base_lr):
+        """sa_m4c.py:349-371"""
+        groups, special = [], set()
+        for m in self.finetune_modules:
+            ps = list(m["module"].parameters())
+            groups.append({"params": ps, "lr": base_lr * m["lr_scale"]})
+            special.update(ps)
+        groups.insert(0, {"params": [p for p in self.parameters() if p not in special]})
+        return groups

@@ -1,0 +1,79 @@
+"""Train-step harness with the reference's step semantics (train.py:133-144, sam/task_utils.py:19-57):
+forward -> masked BCE -> backward -> clip_grad_norm_(0.25) -> Adam(lr groups) -> LambdaLR warm-up/decay,
+running on the flat parameter storage so that clip + Adam + bf16 refresh are two kernels, and the
+data-parallel gradient exchange is a few large RCCL all-reduces (parallel.py)."""
+from bisect import bisect
+
+import torch
+
+from . import ops
+from .autograd import BceLossFn, dropout_clock
+from .params import prepare
+
+
+def lr_lambda(it, warmup_iters=1000, warmup_factor=0.2, lr_decay_iters=(14000, 19000), lr_decay=0.1):
+    """sam/task_utils.py:48-54"""
+    if it <= warmup_iters:
+        alpha = float(it) / float(warmup_iters)
+        return warmup_factor * (1.0 - alpha) + alpha
+    return pow(lr_decay, bisect(list(lr_decay_iters), it))
+
+
+def masked_bce_loss(batch_dict, grad_scale=1.0):
+    """M4CDecodingBCEWithMaskLoss on the score blocks SAM4C.forward left in batch_dict"""
+    return BceLossFn.apply(batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"], batch_dict["targets"], batch_dict["train_loss_mask"], grad_scale)
+
+
+class Trainer:
+    def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0):
+        self.model = model
+        groups = model.get_optimizer_parameters(base_lr)
+        self.group_lr = [g.get("lr", base_lr) for g in groups]
+        self.flat = prepare(model, groups=[g["params"] for g in groups])
+        if len(self.flat.segment_ends) != len(groups):
+            raise RuntimeError("flat storage was prepared without optimizer groups; build the Trainer before the first forward")
+        dev = self.flat.flat.device
+        self.exp_avg = torch.zeros_like(self.flat.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat.flat)
+        self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.max_grad_norm, self.betas, self.eps = max_grad_norm, betas, eps
+        self.schedule = schedule or {}
+        self.reducer = reducer
+        self.global_step = 0
+        dropout_clock.manual_seed(seed)
+
+    def current_lrs(self):
+        lam = lr_lambda(self.global_step, **self.schedule)     # LambdaLR: lr(step) = base * lambda(step), stepped after opt.step()
+        return [lr * lam for lr in self.group_lr]
+
+    def step(self, batch_dict):
+        """one optimisation step; returns the (device, un-synchronised) loss tensor"""
+        model, flat = self.model, self.flat
+        model.train()
+        flat.zero_grad()
+        if self.reducer is not None:
+            self.reducer.begin_step()
+        model(batch_dict)
+        grad_scale = 1.0 / self.reducer.world_size if self.reducer is not None else 1.0
+        loss = masked_bce_loss(batch_dict, grad_scale)
+        loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()                               # waits for the overlapped all-reduces
+        ops.sumsq(flat.grad, self.gnorm_sq)                    # global norm AFTER the all-reduce, as the reference clips reduced grads
+        ops.adam_step(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self.current_lrs(),
+                      self.global_step + 1, gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps)
+        self.global_step += 1
+        return loss.detach()
+
+    # ---- checkpoint in the reference's layout (train.py:177-187) ------------------------------------------
+    def state_dict(self):
+        return {"model_state_dict": {k: v.detach().clone().contiguous() for k, v in self.model.state_dict().items()},
+                "optimizer_state_dict": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.global_step},
+                "global_step": self.global_step}
+
+    def load_model_state_dict(self, sd):
+        """accepts an optional `module.` prefix (DataParallel checkpoints, evaluator.py:182-186)"""
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
+        missing = self.model.load_state_dict(sd, strict=True)
+        self.flat.refresh_shadows()
+        return missing
