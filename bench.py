@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SA-M4C training samples/s on synthetic c=3 batches (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 30 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step = forward + masked BCE + backward + clip_grad_norm_(0.25) + Adam + LR schedule on one synthetic batch of the
+reference's c3 shapes (T=20 + 100 obj + 50 OCR + 12 dec = 182 tokens, 768-d, 12 heads, encoder n,n,s,s,s,s, TextBert 3 layers,
+V=5000), dropout ON (p=0.1 as in the reference), bf16 compute with fp32 master weights, batch 64 per GPU (weak scaling).
+Rank 0 prints ONE JSON line.  At N=1 it also carries `roofline` (dominant kernel, measured with HIP events on the
+launch stream in an instrumented step after the timed region) and `cpu_baseline` (the fp32 oracle timed on host cores)."""
+import argparse
+import json
+import os
+import statistics
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec
+
+
+def build_model(context, layers, vocab, seed=0):
+    from sam_textvqa_amd import modules as M
+    from sam_textvqa_amd import synthetic as S
+    torch.manual_seed(seed)                                  # identical replicas on every rank
+    mcfg = M.BertConfig.from_dict(S.mmt_config_dict(context, layers))
+    tcfg = M.BertConfig.from_dict(S.text_bert_config_dict())
+    return M.SAM4C(mcfg, tcfg, num_answers=vocab, bos_idx=1)
+
+
+def profile_step(trainer, batch):
+    """one instrumented step: HIP events around every C-ABI launch, on the stream the kernels run on"""
+    from sam_textvqa_amd import _capi as capi
+    from sam_textvqa_amd.synthetic import clone_batch
+    capi.profiler = []
+    trainer.step(clone_batch(batch))
+    torch.cuda.synchronize()
+    recs, capi.profiler = capi.profiler, None
+    agg = {}
+    for name, meta, e0, e1 in recs:
+        key = meta.get("kernel", name)
+        a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        a["calls"] += 1
+        a["ms"] += e0.elapsed_time(e1)
+        a["flops"] += meta.get("flops", 0.0)
+        a["bytes"] += meta.get("bytes", 0.0)
+    return agg
+
+
+def roofline_from(agg):
+    total_ms = sum(a["ms"] for a in agg.values())
+    table = []
+    for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
+        row = dict(kernel=k, calls=a["calls"], ms_per_step=round(a["ms"], 4), share=round(a["ms"] / total_ms, 4),
+                   avg_us=round(1e3 * a["ms"] / a["calls"], 2))
+        if a["flops"] and k.startswith("gemm"):
+            row["tflops"] = round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 1)
+        if a["bytes"]:
+            row["gbps"] = round(a["bytes"] / (a["ms"] * 1e-3) / 1e9, 1)
+        table.append(row)
+    top = table[0]
+    a = agg[top["kernel"]]
+    if top["kernel"].startswith("gemm"):
+        ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+        roof = dict(kernel=top["kernel"], bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
+                    traffic=None, avg_launch_us=top["avg_us"], launches_per_step=a["calls"], flops_per_launch=a["flops"] / a["calls"])
+    else:
+        ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+        roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                    traffic=None, avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
+    return roof, table[:12]
+
+
+def cpu_baseline(context, layers, vocab, budget_s=25.0):
+    """the fp32 oracle (a port of the reference, proved equal to it by tests/golden) timed on this host: config 1 of
+    BASELINE.json (B=4).  `faithful` keeps the reference's per-layer mask rebuild and debug torch.unique."""
+    from oracle import sa_m4c_oracle as O
+    from sam_textvqa_amd import synthetic as S
+    threads = int(os.environ.get("SAM_CPU_THREADS", min(os.cpu_count() or 1, 64)))
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    model = O.SAM4C(O.BertConfig.from_dict(S.mmt_config_dict(context, layers)), O.BertConfig.from_dict(S.text_bert_config_dict()), num_answers=vocab)
+    opt, sched = O.make_optimizer(model)
+    batch = S.make_batch(4, vocab=vocab, context=context, device="cpu", seed=99)
+    out = {}
+    for mode in ("faithful", "clean"):
+        O.SpatialBertSelfAttention.faithful = mode == "faithful"
+        model.train()
+        times = []
+        t_end = time.time() + budget_s / 2
+        while len(times) < 4 and (time.time() < t_end or len(times) < 2):
+            t0 = time.time()
+            O.train_step(model, S.clone_batch(batch), opt, sched)
+            times.append(time.time() - t0)
+        out[mode] = 4.0 / statistics.median(times[1:] if len(times) > 1 else times)
+    O.SpatialBertSelfAttention.faithful = False
+    return dict(value=round(out["faithful"], 3), unit="samples/s", cores=threads, kind="port",
+                sample="oracle SAM4C (fp32, torch CPU) full train step, c3 shapes, B=4, median of %d steps after 1 warm-up; 'faithful' variant (reference's per-layer mask rebuild + debug torch.unique)" % 3,
+                clean_variant_samples_per_s=round(out["clean"], 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--context", type=int, default=3)
+    ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    from sam_textvqa_amd import parallel
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    rank, local, world = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
+    dev = torch.device("cuda", local)
+    layers = ("n", "n", "s", "s", "s", "s")
+    model = build_model(args.context, layers, args.vocab)
+    trainer = Trainer(model, seed=1234 + rank)
+    batch = make_batch(args.batch, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
+
+    for _ in range(args.warmup):
+        loss = trainer.step(clone_batch(batch))
+    torch.cuda.synchronize()
+    if world > 1:
+        parallel.dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(clone_batch(batch))
+    torch.cuda.synchronize()
+    if world > 1:
+        parallel.dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        parallel.dist.all_reduce(t, op=parallel.dist.ReduceOp.MAX)
+        dt = t.item()
+    final_loss = float(loss.item())
+    if rank != 0:
+        if world > 1:
+            parallel.dist.barrier()
+            parallel.dist.destroy_process_group()
+        return
+    gb = args.batch * world
+    res = {
+        "metric": "training samples/sec, SA-M4C c=%d synthetic batch" % args.context, "value": round(gb * args.steps / dt, 2), "unit": "samples/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": "SA-M4C c=%d full train step (fwd + masked BCE + bwd + clip 0.25 + Adam + LR), T=20 + 100 obj + 50 OCR + 12 dec = 182 tokens, "
+                               "768-d, 12 heads, MMT n,n,s,s,s,s + TextBert 3 layers + input encoders + classifier(V=%d)/pointer net, dropout 0.1 on, "
+                               "bf16 MFMA compute, fp32 master weights/Adam" % (args.context, args.vocab),
+                   "global_batch": gb, "per_gpu_batch": args.batch, "seq_len": 182, "parallelism": "dp%d" % world},
+        "final_loss": final_loss,
+        "train_gflop_per_sample": 52.9,
+        "mfma_fraction_whole_step": round(gb * args.steps / dt * 52.9e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+    }
+    if world == 1 and not args.no_roofline:
+        roof, table = roofline_from(profile_step(trainer, batch))
+        res["roofline"] = roof
+        res["kernels"] = table
+    if world == 1 and not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(args.context, layers, args.vocab)
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        parallel.dist.barrier()
+        parallel.dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

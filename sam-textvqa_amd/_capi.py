@@ -18,7 +18,7 @@ class GemmDesc(C.Structure):
                 ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("bias", _vp), ("residual", _vp), ("ldr", _i64),
                 ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i64),
-                ("p_drop", _f), ("seed", _u64), ("offset", _u64)]
+                ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64)]
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)
@@ -62,6 +62,12 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise SamHipError("libsam_hip.so not built (%s): run `python __graft_entry__.py` or "
                               "sam_textvqa_amd._build.build(); there is no fallback path" % LIB_PATH)
+        # torch bundles its own libamdhip64; load it FIRST so libsam_hip.so binds to the same HIP runtime instance that
+        # owns torch's device allocations and streams (a second runtime copy sees "no ROCm-capable device")
+        import torch
+        hip_rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(hip_rt):
+            C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
         l = C.CDLL(LIB_PATH)
         l.sam_last_error.restype = C.c_char_p
         for name, args in SIGNATURES.items():
@@ -72,10 +78,21 @@ def lib():
     return _lib
 
 
-def call(name, *args):
+profiler = None   # bench.py sets this to a list to collect (name, meta, start_event, end_event) per C-ABI call
+
+
+def call(name, *args, meta=None):
     """invoke a status-returning entry point; non-zero -> SamHipError with the library's message"""
     l = lib()
-    rc = getattr(l, name)(*args)
+    if profiler is not None and name not in NO_STATUS:
+        import torch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = getattr(l, name)(*args)
+        e1.record()
+        profiler.append((name, meta or {}, e0, e1))
+    else:
+        rc = getattr(l, name)(*args)
     if name not in NO_STATUS and rc != 0:
         raise SamHipError("%s failed (rc=%d): %s" % (name, rc, l.sam_last_error().decode()))
     return rc

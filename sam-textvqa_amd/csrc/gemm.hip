@@ -1,7 +1,10 @@
 // bf16 MFMA GEMM with fused epilogues for the nn.Linear sites of the SA-M4C path (gfx950).
 //
 // 128x128x64 block tile, 256 threads = 2x2 waves of 64x64, v_mfma_f32_16x16x32_bf16, fp32 accumulate.
-// Operands are staged global -> registers -> LDS (next tile's loads are in flight during the MFMAs).
+// Operands go global -> LDS directly (global_load_lds_dwordx4, no VGPR staging, no ds_write pass) into a
+// double-buffered LDS image: the DMA of k-tile t+1 is in flight during the MFMAs of tile t, one barrier per tile.
+// The LDS image is XOR-swizzled; since the DMA writes lane-linear, the swizzle is applied to each lane's SOURCE
+// address.  Only a partial last k-tile (K % 64 != 0) takes the predicated register-staged path.
 // Either operand may be stored k-contiguous (fragments by ds_read_b128/b64) or k-strided (row index =
 // contraction index: fragments by ds_read_b64_tr_b16), which gives forward / dgrad / wgrad from one
 // template without any transpose pass through HBM.
@@ -26,6 +29,9 @@ struct GemmArgs {
   unsigned thr16; float inv_keep;
   unsigned seed_lo, seed_hi, off_lo, off_hi;
   int tiles_m, tiles_n;
+  int split_k;        // >1: grid = tiles * split_k; split s stores its fp32 partial tile into ws[s] (wgrad: few tiles, very long K)
+  float* ws;          // [split_k][M*N] partial outputs, then [split_k][M] partial bias gradients; reduced by splitk_reduce_kernel
+  float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
 };
 
 // ---- LDS images --------------------------------------------------------------------------------
@@ -59,6 +65,31 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, const uint4 (&r)[
   }
 }
 
+// direct-to-LDS tile fill.  One wave instruction writes 1 KB lane-linearly: lane l lands at byte 16*l of the slice, so
+// lane l must FETCH the chunk that the swizzled image keeps there.  Rows / columns past the matrix edge are clamped to
+// the last valid one: they only feed output rows/cols that are never stored.  K must cover the whole 64-wide tile.
+template <bool KC>
+__device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base, int64_t ld, int row0, int rows, int k0, int wave, int lane) {
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int j = wave * 4 + jj;  // 1 KB slice index 0..15
+    const bf16_t* src;
+    if (KC) {
+      const int row = 8 * j + (lane >> 3), pos = lane & 7;
+      const int c = pos ^ ((row >> 1) & 7);
+      const int grow = min(row0 + row, rows - 1);
+      src = base + (int64_t)grow * ld + k0 + c * 8;
+    } else {
+      const int krow = 4 * j + (lane >> 4), pos = lane & 15;
+      const int cc = pos ^ ((krow & 7) << 1);
+      const int col = min(row0 + cc * 8, rows - 8);
+      src = base + (int64_t)(k0 + krow) * ld + col;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + j * 1024), 16, 0, 0);
+  }
+}
+
 // fragment of 16 rows (row0..row0+15 of the operand's M/N index) x 32 k (step ks) for lane (i,g).
 // NATURAL k map (both operands k-contiguous): k = 32ks + 8g + e.
 // SPLIT k map (any operand k-strided):        k = 32ks + 16(e>>2) + 4g + (e&3)   -- both operands must agree.
@@ -85,8 +116,10 @@ template <> struct Store4<bf16_t> {
   }
 };
 template <> struct Store4<float> {
+  // accumulate: 0 = store, 1 = read-modify-write (every element has exactly one writer)
   static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int accumulate) {
-    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx);
+    float* f = reinterpret_cast<float*>(C) + idx;
+    float4* p = reinterpret_cast<float4*>(f);
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (accumulate) { const float4 c = *p; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
     *p = o;
@@ -95,9 +128,8 @@ template <> struct Store4<float> {
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BM * BK * 2];
-  unsigned char* As = smem;
-  unsigned char* Bs = smem + BM * BK * 2;
+  constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand per stage
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // [stage][A|B]
   constexpr bool SPLIT = !(AKC && BKC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   const int wm = wave & 1, wn = wave >> 1;
@@ -105,7 +137,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles (n fastest) so the
   // tiles that share an A panel / the whole B panel meet in one L2.
   const int nblk = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x;
+  int bid = blockIdx.x % nblk;
+  const int split = blockIdx.x / nblk;
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -118,18 +151,39 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[4], rb[4];
-  load_tile<AKC>(ra, p.A, p.lda, m0, p.M, 0, p.K, tid);
-  load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, 0, p.K, tid);
-  const int KT = (p.K + BK - 1) / BK;
-  for (int kt = 0; kt < KT; ++kt) {
-    store_tile<AKC>(As, ra, tid);
-    store_tile<BKC>(Bs, rb, tid);
-    __syncthreads();
-    if (kt + 1 < KT) {  // next tile's global loads fly during the MFMAs below
-      load_tile<AKC>(ra, p.A, p.lda, m0, p.M, (kt + 1) * BK, p.K, tid);
-      load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, (kt + 1) * BK, p.K, tid);
+  const int KT_all = (p.K + BK - 1) / BK;
+  const int per = (KT_all + p.split_k - 1) / p.split_k;
+  const int kt_begin = split * per, KT = min(KT_all, kt_begin + per);
+  if (kt_begin >= KT) return;   // whole block leaves together: no barrier has been reached
+  const bool do_bias = !AKC && p.bias_grad != nullptr && n0 == 0 && wn == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const short one_bf16 = (short)0x3F80;
+  const bf16x8 ones = {one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16};
+
+  const int KT_full = p.K / BK;   // k-tiles that are entirely inside K: direct-to-LDS; a partial last tile is register staged
+  auto fill = [&](int kt, int stage) {
+    unsigned char* As_ = smem + stage * 2 * TILE_BYTES;
+    unsigned char* Bs_ = As_ + TILE_BYTES;
+    if (kt < KT_full) {
+      glds_tile<AKC>(As_, p.A, p.lda, m0, p.M, kt * BK, wave, lane);
+      glds_tile<BKC>(Bs_, p.B, p.ldb, n0, p.N, kt * BK, wave, lane);
+    } else {
+      uint4 ra[4], rb[4];
+      load_tile<AKC>(ra, p.A, p.lda, m0, p.M, kt * BK, p.K, tid);
+      load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, kt * BK, p.K, tid);
+      store_tile<AKC>(As_, ra, tid);
+      store_tile<BKC>(Bs_, rb, tid);
     }
+  };
+  fill(kt_begin, 0);
+  for (int kt = kt_begin; kt < KT; ++kt) {
+    const int stage = (kt - kt_begin) & 1;
+    __syncthreads();   // tile kt has landed (the compiler drains vmcnt before the barrier) and everyone left stage^1
+    if (kt + 1 < KT) fill(kt + 1, stage ^ 1);
+    const unsigned char* As = smem + stage * 2 * TILE_BYTES;
+    const unsigned char* Bs = As + TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[4], bf[4];
@@ -143,10 +197,25 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
 #pragma unroll
         for (int tm = 0; tm < 4; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
+      if (do_bias) {  // D[n][m] = sum_k 1 * A(m,k): every row n holds the column sums of this wave's 64 m
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[tm], accb[tm], 0, 0, 0);
+      }
     }
-    __syncthreads();
   }
 
+  if (do_bias && g == 0) {   // each m has exactly one writer per split: no atomics
+    float* bdst = p.split_k > 1 ? p.ws + (int64_t)p.split_k * p.M * p.N + (int64_t)split * p.M : p.bias_grad;
+#pragma unroll
+    for (int tm = 0; tm < 4; ++tm) {
+      const int m = m0 + wm * 64 + tm * 16 + i;
+      if (m < p.M) bdst[m] = p.split_k > 1 ? accb[tm][0] : bdst[m] + accb[tm][0];
+    }
+  }
+  void* Cout = p.C;
+  int64_t ldc = p.ldc;
+  int accumulate = p.accumulate;
+  if (p.split_k > 1) { Cout = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; accumulate = 0; }
   // epilogue: lane owns rows m = m0 + wm*64 + tm*16 + i, columns n = n0 + wn*64 + tn*16 + 4g .. +3
 #pragma unroll
   for (int tm = 0; tm < 4; ++tm) {
@@ -187,14 +256,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
           v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
         }
       }
-      Store4<OutT>::st(p.C, (int64_t)m * p.ldc + n, v, p.accumulate);
+      Store4<OutT>::st(Cout, (int64_t)m * ldc + n, v, accumulate);
+    }
+  }
+}
+
+// C[m,n] += sum_s ws[s][m,n]; bias_grad[m] += sum_s wsb[s][m]   (fixed summation order: reproducible)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int S, int M, int N, float* C, int64_t ldc, float* bias_grad) {
+  const int64_t mn4 = (int64_t)M * N / 4;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(ws)[i];
+    for (int s = 1; s < S; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(ws + (int64_t)s * M * N)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int64_t e = i * 4, m = e / N, n = e - m * N;
+    float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
+    const float4 c = *dst;
+    *dst = make_float4(c.x + a.x, c.y + a.y, c.z + a.z, c.w + a.w);
+  }
+  if (bias_grad) {
+    const float* wsb = ws + (int64_t)S * M * N;
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+      float a = 0.f;
+      for (int s = 0; s < S; ++s) a += wsb[(int64_t)s * M + m];
+      bias_grad[m] += a;
     }
   }
 }
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int launch(const GemmArgs& a, hipStream_t st) {
-  gemm_kernel<AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n), dim3(256), 0, st>>>(a);
+  gemm_kernel<AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(256), 0, st>>>(a);
+  if (a.split_k > 1) {
+    const int64_t mn4 = (int64_t)a.M * a.N / 4;
+    splitk_reduce_kernel<<<dim3((unsigned)min((int64_t)2048, (mn4 + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.split_k, a.M, a.N, (float*)a.C, a.ldc, a.bias_grad);
+  }
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -222,6 +319,27 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.inv_keep = a.thr16 ? 1.0f / (1.0f - (float)a.thr16 / 65536.0f) : 1.0f;
   a.seed_lo = (unsigned)d->seed; a.seed_hi = (unsigned)(d->seed >> 32); a.off_lo = (unsigned)d->offset; a.off_hi = (unsigned)(d->offset >> 32);
   a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
+  a.split_k = 1;
+  a.bias_grad = d->bias_grad;
+  SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
+  if (d->split_k != 0 && d->split_k != 1) {
+    SAM_REQUIRE(d->c_is_f32 && d->epilogue == SAM_EPI_NONE && d->accumulate, "sam_gemm_bf16: split_k needs an fp32 C with accumulate=1 and no epilogue");
+    SAM_REQUIRE(d->ws && ((uintptr_t)d->ws % 16 == 0), "sam_gemm_bf16: split_k needs a 16-byte aligned workspace");
+    const int kt = (d->K + BK - 1) / BK, tiles = a.tiles_m * a.tiles_n;
+    const int64_t per_split = ((int64_t)d->M * d->N + d->M) * (int64_t)sizeof(float);
+    int s = d->split_k;
+    if (s < 0) {  // auto: ~3 workgroups per CU, at least 4 k-tiles per split
+      s = (768 + tiles - 1) / tiles;
+      if (s > kt / 4) s = kt / 4;
+      if (s > 32) s = 32;
+    }
+    if (s > kt) s = kt;
+    if ((int64_t)s * per_split > d->ws_bytes) s = (int)(d->ws_bytes / per_split);
+    SAM_REQUIRE(d->split_k < 0 || s == d->split_k || s >= kt, "sam_gemm_bf16: workspace too small for split_k=%d (%lld bytes)", d->split_k, (long long)d->ws_bytes);
+    if (s < 1) s = 1;
+    a.split_k = s;
+    a.ws = d->ws;
+  }
   hipStream_t st = (hipStream_t)stream;
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;

@@ -12,7 +12,7 @@
 
 namespace {
 
-constexpr int LN_PARTIAL_BLOCKS = 256;
+constexpr int LN_PARTIAL_BLOCKS = 512;
 
 template <typename T> struct Ld4;
 template <> struct Ld4<bf16_t> {
@@ -155,13 +155,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
   }
 }
 
-// out[c] (+)= sum_r ws[r*stride + c]   (deterministic order)
-__global__ void partial_finalize_kernel(const float* ws, int nrows, int64_t stride, int ncols, float* out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= ncols) return;
+// out[c] (+)= sum_r ws[r*stride + c]   (deterministic order).  64 columns x 4 row lanes per block; grid.y selects one of up to three
+// (column offset, output) pairs so the LN backward finishes dgamma/dbeta/dbias in one launch.
+struct FinalizeOuts { float* out[3]; int64_t col0[3]; };
+__global__ __launch_bounds__(256) void partial_finalize_kernel(const float* ws, int nrows, int64_t stride, int ncols, FinalizeOuts o, int accumulate) {
+  __shared__ float red[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  const float* base = ws + o.col0[blockIdx.y];
   float s = 0.f;
-  for (int r = 0; r < nrows; ++r) s += ws[(int64_t)r * stride + c];
-  out[c] = accumulate ? out[c] + s : s;
+  if (c < ncols) {
+    int r = ry;
+    for (; r + 28 < nrows; r += 32) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = base[(int64_t)(r + 4 * u) * stride + c];
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+    for (; r < nrows; r += 4) s += base[(int64_t)r * stride + c];
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (ry == 0 && c < ncols) {
+    const float tot = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+    float* out = o.out[blockIdx.y];
+    out[c] = accumulate ? out[c] + tot : tot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------ colsum
@@ -172,7 +190,15 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* x, in
   const int rows_per = (M + COLSUM_CHUNKS - 1) / COLSUM_CHUNKS;
   const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
   float a[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int r = r0; r < r1; ++r) {
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8][4];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) Ld4<bf16_t>::ld(x, (int64_t)(r + u) * ldx + 4 * c4, v[u]);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { a[0] += v[u][0]; a[1] += v[u][1]; a[2] += v[u][2]; a[3] += v[u][3]; }
+  }
+  for (; r < r1; ++r) {
     float v[4];
     Ld4<bf16_t>::ld(x, (int64_t)r * ldx + 4 * c4, v);
     a[0] += v[0]; a[1] += v[1]; a[2] += v[2]; a[3] += v[3];
@@ -220,15 +246,14 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ld
 // scores[b,s,o] = scale * <q[b,s,:], k[b,o,:]> + (1 - mask[b,o]) * -10000     (fp32, literal -10000 kept: it is an OUTPUT)
 __global__ __launch_bounds__(256) void ptr_fwd_kernel(const bf16_t* q, const bf16_t* k, const uint8_t* mask, int S, int No, int D, float scale,
                                                       float* out, int64_t ldo_b, int64_t ldo_s) {
-  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bf16_t* qb = q + (int64_t)b * S * D;
+  const int b = blockIdx.x, s = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bf16_t* qrow = q + ((int64_t)b * S + s) * D;
   const bf16_t* kb = k + (int64_t)b * No * D;
-  for (int p = wave; p < S * No; p += 4) {  // one wave per (s, o) pair: 64-lane dot product over D
-    const int s = p / No, o = p - s * No;
+  for (int o = wave; o < No; o += 4) {  // one wave per (s, o) pair: 64-lane dot product over D
     float acc = 0.f;
     for (int c = lane; c * 4 < D; c += 64) {
       float a[4], bb[4];
-      Ld4<bf16_t>::ld(qb, (int64_t)s * D + 4 * c, a);
+      Ld4<bf16_t>::ld(qrow, 4 * c, a);
       Ld4<bf16_t>::ld(kb, (int64_t)o * D + 4 * c, bb);
       acc += a[0] * bb[0] + a[1] * bb[1] + a[2] * bb[2] + a[3] * bb[3];
     }
@@ -236,36 +261,27 @@ __global__ __launch_bounds__(256) void ptr_fwd_kernel(const bf16_t* q, const bf1
     if (lane == 0) out[(int64_t)b * ldo_b + (int64_t)s * ldo_s + o] = acc * scale + (mask[(int64_t)b * No + o] ? 0.f : -10000.0f);
   }
 }
-// dq[b,s,:] = scale * sum_o ds[b,s,o] k[b,o,:] ; dk[b,o,:] = scale * sum_s ds[b,s,o] q[b,s,:]
+// dq[b,s,:] = scale * sum_o ds[b,s,o] k[b,o,:] ; dk[b,o,:] = scale * sum_s ds[b,s,o] q[b,s,:]   (one block per output row)
 __global__ __launch_bounds__(256) void ptr_bwd_kernel(const float* ds, int64_t ld_b, int64_t ld_s, const bf16_t* q, const bf16_t* k, int S, int No, int D,
                                                       float scale, bf16_t* dq, bf16_t* dk) {
-  extern __shared__ float sds[];  // [S*No]
-  const int b = blockIdx.x;
-  for (int p = threadIdx.x; p < S * No; p += 256) sds[p] = ds[(int64_t)b * ld_b + (int64_t)(p / No) * ld_s + (p % No)] * scale;
+  __shared__ float w[256];
+  const int b = blockIdx.x, row = blockIdx.y;
+  const bool is_q = row < S;
+  const int nsum = is_q ? No : S;
+  const int o_fixed = row - S;
+  for (int t = threadIdx.x; t < nsum; t += 256)
+    w[t] = (is_q ? ds[(int64_t)b * ld_b + (int64_t)row * ld_s + t] : ds[(int64_t)b * ld_b + (int64_t)t * ld_s + o_fixed]) * scale;
   __syncthreads();
-  const bf16_t* qb = q + (int64_t)b * S * D;
-  const bf16_t* kb = k + (int64_t)b * No * D;
+  const bf16_t* src = is_q ? k + (int64_t)b * No * D : q + (int64_t)b * S * D;
+  bf16_t* dst = is_q ? dq + ((int64_t)b * S + row) * D : dk + ((int64_t)b * No + o_fixed) * D;
   for (int c = threadIdx.x; c * 4 < D; c += 256) {
-    for (int s = 0; s < S; ++s) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int o = 0; o < No; ++o) {
-        float kv[4];
-        Ld4<bf16_t>::ld(kb, (int64_t)o * D + 4 * c, kv);
-        const float w = sds[s * No + o];
-        a[0] += w * kv[0]; a[1] += w * kv[1]; a[2] += w * kv[2]; a[3] += w * kv[3];
-      }
-      st4_bf16(dq, ((int64_t)b * S + s) * D + 4 * c, a);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < nsum; ++t) {
+      float v[4];
+      Ld4<bf16_t>::ld(src, (int64_t)t * D + 4 * c, v);
+      a[0] += w[t] * v[0]; a[1] += w[t] * v[1]; a[2] += w[t] * v[2]; a[3] += w[t] * v[3];
     }
-    for (int o = 0; o < No; ++o) {
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < S; ++s) {
-        float qv[4];
-        Ld4<bf16_t>::ld(qb, (int64_t)s * D + 4 * c, qv);
-        const float w = sds[s * No + o];
-        a[0] += w * qv[0]; a[1] += w * qv[1]; a[2] += w * qv[2]; a[3] += w * qv[3];
-      }
-      st4_bf16(dk, ((int64_t)b * No + o) * D + 4 * c, a);
-    }
+    st4_bf16(dst, 4 * c, a);
   }
 }
 
@@ -383,13 +399,9 @@ extern "C" int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int
                     : ln_bwd_dispatch<bf16_t>(nch, dim3(nblk), st, (const bf16_t*)dy, ldd, x, ldx, mean, rstd, gamma, M, D, (bf16_t*)dx, dxd, ldo, thr16, inv_keep, seed, offset, ws);
   if (rc) return rc;
   SAM_LAUNCH_CHECK();
-  const dim3 fg((D + 255) / 256);
-  partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, dgamma, accumulate);
-  partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws + D, nblk, 3 * (int64_t)D, D, dbeta, accumulate);
   // dbias of the dense in front of this LN = column sums of the (dropout-masked) dx
-  if (dbias) {
-    partial_finalize_kernel<<<fg, dim3(256), 0, st>>>(ws + 2 * D, nblk, 3 * (int64_t)D, D, dbias, accumulate);
-  }
+  FinalizeOuts fo = {{dgamma, dbeta, dbias}, {0, D, 2 * (int64_t)D}};
+  partial_finalize_kernel<<<dim3((D + 63) / 64, dbias ? 3 : 2), dim3(256), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, fo, accumulate);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -401,7 +413,8 @@ extern "C" int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* 
   SAM_REQUIRE(M > 0 && N > 0 && N % 4 == 0 && ldx % 4 == 0, "sam_colsum_bf16: need N %% 4 == 0 (M=%d N=%d)", M, N);
   hipStream_t st = (hipStream_t)stream;
   colsum_partial_kernel<<<dim3((N / 4 + 255) / 256, COLSUM_CHUNKS), dim3(256), 0, st>>>((const bf16_t*)x, ldx, M, N, ws);
-  partial_finalize_kernel<<<dim3((N + 255) / 256), dim3(256), 0, st>>>(ws, COLSUM_CHUNKS, N, N, out, accumulate);
+  FinalizeOuts fo = {{out, nullptr, nullptr}, {0, 0, 0}};
+  partial_finalize_kernel<<<dim3((N + 63) / 64, 1), dim3(256), 0, st>>>(ws, COLSUM_CHUNKS, N, N, fo, accumulate);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -426,15 +439,15 @@ extern "C" int sam_ptr_scores_fwd(const void* q, const void* k, const uint8_t* o
                                   int64_t ld_out_b, int64_t ld_out_s, void* stream) {
   SAM_REQUIRE(q && k && ocr_mask && out, "sam_ptr_scores_fwd: null pointer");
   SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0, "sam_ptr_scores_fwd: bad shape");
-  ptr_fwd_kernel<<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
+  ptr_fwd_kernel<<<dim3(B, S), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
 extern "C" int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const void* q, const void* k, int B, int S, int No, int D, float scale,
                                   void* dq, void* dk, void* stream) {
   SAM_REQUIRE(dscores && q && k && dq && dk, "sam_ptr_scores_bwd: null pointer");
-  SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0 && (size_t)S * No * 4 <= 64 * 1024, "sam_ptr_scores_bwd: bad shape");
-  ptr_bwd_kernel<<<dim3(B), dim3(256), (size_t)S * No * sizeof(float), (hipStream_t)stream>>>(dscores, ld_b, ld_s, (const bf16_t*)q, (const bf16_t*)k, S, No, D,
+  SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0 && S <= 256 && No <= 256, "sam_ptr_scores_bwd: bad shape (S, No <= 256)");
+  ptr_bwd_kernel<<<dim3(B, S + No), dim3(256), 0, (hipStream_t)stream>>>(dscores, ld_b, ld_s, (const bf16_t*)q, (const bf16_t*)k, S, No, D,
                                                                                           scale, (bf16_t*)dq, (bf16_t*)dk);
   SAM_LAUNCH_CHECK();
   return SAM_OK;

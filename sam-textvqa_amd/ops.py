@@ -78,8 +78,11 @@ def attn_fwd(qkv, allow, batch, n_heads, scale, p_drop=0.0, seed=0, offset=0):
     lse2 = torch.empty((batch, n_heads, n), dtype=torch.float32, device=qkv.device)
     keep = torch.empty((batch, n_heads, n, allow.shape[-1]), dtype=torch.int32, device=qkv.device) if p_drop > 0 else None
     sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    nw = allow.shape[-1]
+    alg_bytes = batch * (4 * n * d_model * 2 + n_heads * n * nw * 4 * (2 if p_drop > 0 else 1) + n_heads * n * 4)
     capi.call("sam_attn_fwd", capi.ptr(qkv), capi.ptr(allow), allow.stride(0), sh, batch, n, n_heads, d_model // n_heads,
-              float(scale), float(p_drop), int(seed), int(offset), capi.ptr(out), capi.ptr(lse2), capi.ptr(keep), capi.stream_handle())
+              float(scale), float(p_drop), int(seed), int(offset), capi.ptr(out), capi.ptr(lse2), capi.ptr(keep), capi.stream_handle(),
+              meta=dict(kernel="attn_fwd", bytes=alg_bytes, flops=4.0 * batch * n * n * d_model, shape=(batch, n, n_heads)))
     return out, lse2, keep
 
 
@@ -94,7 +97,9 @@ def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0):
     sh = 0 if allow.shape[1] == 1 else allow.stride(1)
     capi.call("sam_attn_bwd", capi.ptr(dout), capi.ptr(qkv), capi.ptr(lse2), capi.ptr(allow), allow.stride(0), sh,
               capi.ptr(keep), batch, n, n_heads, d_model // n_heads, float(scale), float(p_drop), capi.ptr(dqkv), capi.ptr(delta),
-              capi.stream_handle())
+              capi.stream_handle(),
+              meta=dict(kernel="attn_bwd(dq+dkdv)", flops=10.0 * batch * n * n * d_model, shape=(batch, n, n_heads),
+                        bytes=batch * (8 * n * d_model * 2 + n_heads * n * (allow.shape[-1] * 4 * (2 if keep is not None else 1) + 8))))
     return dqkv
 
 
@@ -104,7 +109,7 @@ def _dp(t):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=None, out_dtype=BF16, epilogue=capi.EPI_NONE,
-         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0):
+         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0, split_k=0, bias_grad=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(k,n)); see include/sam_hip.h `sam_gemm_bf16` for layouts and epilogues.
     a, b: 2-D bf16 tensors whose LAST dim is contiguous (row stride = leading dimension)."""
     for t, nm in ((a, "A"), (b, "B")):
@@ -126,7 +131,13 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     aux = aux_out if aux_out is not None else aux_in
     d.ld_aux = aux.stride(0) if aux is not None else 0
     d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
-    capi.call("sam_gemm_bf16", d, capi.stream_handle())
+    d.split_k, d.bias_grad = int(split_k), _dp(bias_grad)
+    if split_k not in (0, 1):
+        want = split_k if split_k > 0 else 32
+        ws = _workspace(min(want * (M * N + M) * 4, 96 << 20), a.device, "splitk")
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+    capi.call("sam_gemm_bf16", d, capi.stream_handle(),
+              meta=dict(kernel="gemm<a_kc=%d,b_kc=%d,epi=%d,f32=%d>" % (d.a_kcontig, d.b_kcontig, d.epilogue, d.c_is_f32), flops=2.0 * M * N * K, shape=(M, N, K)))
     return out
 
 

@@ -1,0 +1,106 @@
+"""Data-parallel gradient exchange: one process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm) over xGMI.
+
+The reference's only strategy is single-process nn.DataParallel (train.py:111-112: per-step parameter broadcast +
+gradient reduce to GPU0).  Here every rank keeps a full replica (same seed-0 weights), shards the batch, and the flat
+fp32 gradient buffer (params.py) is all-reduced in a few large contiguous buckets — no per-parameter messages, no
+broadcast per step.  Buckets are walked from the END of the buffer (the last layers finish their backward first);
+with overlap=True each bucket's all-reduce is issued on a side stream as soon as the layers covering it have run their
+backward (EncoderLayerFn.backward calls `layer_done`), hiding the exchange behind the remaining backward GEMMs.
+xGMI is point-to-point (7 links x ~153 GB/s per GPU): large buckets (default 64 MB) keep RCCL's ring/tree per-link
+bound instead of latency bound; 386 MB of fp32 gradients = 6 buckets.
+The loss normaliser max(sum(loss_mask),1) is per rank here (per global batch under DataParallel, task_utils.py:28-29);
+gradients are pre-scaled by 1/world in the loss kernel so the all-reduce SUM is the mean of per-rank gradients."""
+import torch
+import torch.distributed as dist
+
+
+class GradReducer:
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None):
+        self.grad = flat_grad
+        self.group = group
+        self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = flat_grad.numel()
+        per = max(1, bucket_bytes // flat_grad.element_size())
+        # bucket k covers [n - (k+1)*per, n - k*per): ascending k = descending addresses = backward order
+        self.buckets = []
+        hi = n
+        while hi > 0:
+            lo = max(0, hi - per)
+            self.buckets.append((lo, hi))
+            hi = lo
+        self.overlap = overlap and flat_grad.is_cuda and self.world_size > 1
+        self.stream = torch.cuda.Stream() if self.overlap else None
+        self.regions = []
+        self.begin_step()
+
+    def register_regions(self, ranges):
+        """[lo, hi) flat ranges of the encoder layers; returns region ids in the order given.  A bucket is released once
+        every registered region at or above its low end has reported `mark_done` (layers may finish in any order)."""
+        order = sorted(range(len(ranges)), key=lambda i: -ranges[i][0])
+        self.regions = [ranges[i] for i in order]
+        ids = [0] * len(ranges)
+        for pos, i in enumerate(order):
+            ids[i] = pos
+        self.begin_step()
+        return ids
+
+    def mark_done(self, region_id):
+        self.done[region_id] = True
+        while self.done_ptr < len(self.regions) and self.done[self.done_ptr]:
+            self.done_ptr += 1
+        if self.done_ptr > 0:
+            self.region_done(self.regions[self.done_ptr - 1][0])
+
+    def begin_step(self):
+        self.next_bucket = 0
+        self.ready_lo = self.grad.numel()      # gradients at addresses >= ready_lo are final
+        self.work = []
+        self.done = [False] * len(self.regions)
+        self.done_ptr = 0
+
+    def _launch(self, k):
+        lo, hi = self.buckets[k]
+        chunk = self.grad[lo:hi]
+        if self.world_size == 1:
+            return
+        if self.overlap:
+            self.stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.stream):
+                self.work.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+
+    def region_done(self, lo):
+        """everything at flat offsets >= lo has its final gradient: launch every bucket that is now complete"""
+        self.ready_lo = min(self.ready_lo, lo)
+        while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket][0] >= self.ready_lo:
+            self._launch(self.next_bucket)
+            self.next_bucket += 1
+
+    def finish(self):
+        """after backward: reduce whatever is left, then make the compute stream wait for the exchange"""
+        self.region_done(0)
+        for w in self.work:
+            w.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.stream)
+        self.work = []
+
+
+active_reducer = None   # set by the Trainer; EncoderLayerFn.backward reports finished layers to it
+
+
+def init_distributed():
+    """read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run contract)"""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    return rank, local, world

@@ -23,7 +23,8 @@ def _round_up(x, a):
 
 
 def _ordered_params(module):
-    """parameters in allocation order: q/k/v of every attention block adjacent; otherwise registration order"""
+    """registration order (so every layer's parameters stay contiguous), except that the six q/k/v tensors of an
+    attention block are emitted as [Wq, Wk, Wv, bq, bk, bv] so the fused QKV projection sees one [3D, D] operand"""
     seen, order = set(), []
 
     def add(p):
@@ -31,14 +32,15 @@ def _ordered_params(module):
             seen.add(id(p))
             order.append(p)
 
+    qkv_of = {}
     for m in module.modules():
         if all(hasattr(m, n) for n in ("query", "key", "value")) and hasattr(m, "num_attention_heads"):
-            for n in ("query", "key", "value"):
-                add(getattr(m, n).weight)
-            for n in ("query", "key", "value"):
-                add(getattr(m, n).bias)
+            six = [getattr(m, n).weight for n in ("query", "key", "value")] + [getattr(m, n).bias for n in ("query", "key", "value")]
+            for p in six:
+                qkv_of[id(p)] = six
     for p in module.parameters():
-        add(p)
+        for q in qkv_of.get(id(p), (p,)):
+            add(q)
     return order
 
 
@@ -109,6 +111,15 @@ class FlatParams:
 
     def zero_grad(self):
         self.grad.zero_()
+
+    def range_of(self, module):
+        """[start, end) element range of the flat buffers covering `module`'s parameters (they are contiguous)"""
+        idx = sorted(p._sam_index for p in module.parameters())
+        if not idx or idx != list(range(idx[0], idx[-1] + 1)):
+            raise ValueError("module parameters are not contiguous in flat storage")
+        o0 = self.layout[idx[0]][0]
+        o, r, c, s_ = self.layout[idx[-1]]
+        return o0, o + r * s_
 
     # ---- fused views -----------------------------------------------------------------------------
     @staticmethod

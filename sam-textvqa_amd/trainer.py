@@ -6,7 +6,7 @@ from bisect import bisect
 
 import torch
 
-from . import ops
+from . import ops, parallel
 from .autograd import BceLossFn, dropout_clock
 from .params import prepare
 
@@ -38,7 +38,14 @@ class Trainer:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.max_grad_norm, self.betas, self.eps = max_grad_norm, betas, eps
         self.schedule = schedule or {}
+        if reducer is None and parallel.dist.is_initialized() and parallel.dist.get_world_size() > 1:
+            reducer = parallel.GradReducer(self.flat.grad)
         self.reducer = reducer
+        if reducer is not None:
+            enc = getattr(getattr(model, "mmt", None), "encoder", None)
+            layers = [l for name in ("normal_layers", "spatial_layers", "implicit_layers") for l in getattr(enc, name, [])] if enc is not None else []
+            for layer, rid in zip(layers, reducer.register_regions([self.flat.range_of(l) for l in layers])):
+                layer._sam_region_id = rid
         self.global_step = 0
         dropout_clock.manual_seed(seed)
 
@@ -53,10 +60,12 @@ class Trainer:
         flat.zero_grad()
         if self.reducer is not None:
             self.reducer.begin_step()
+        parallel.active_reducer = self.reducer
         model(batch_dict)
         grad_scale = 1.0 / self.reducer.world_size if self.reducer is not None else 1.0
         loss = masked_bce_loss(batch_dict, grad_scale)
         loss.backward()
+        parallel.active_reducer = None
         if self.reducer is not None:
             self.reducer.finish()                               # waits for the overlapped all-reduces
         ops.sumsq(flat.grad, self.gnorm_sq)                    # global norm AFTER the all-reduce, as the reference clips reduced grads

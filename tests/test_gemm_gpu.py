@@ -103,6 +103,24 @@ def test_wgrad_layout(R, M, N):
     assert_close_bf16(dw, 2 * ref, ulps=0, name="wgrad accumulate")
 
 
+@pytest.mark.parametrize("R,M,N,split", [(11648, 768, 768, -1), (1000, 2304, 768, 4), (182, 768, 3072, -1), (5000, 768, 8, 7), (728, 5000, 768, -1)])
+def test_wgrad_split_k_and_fused_bias_grad(R, M, N, split):
+    ops, capi = _mods()
+    dy, x = rnd((R, M), 18), rnd((R, N), 19)
+    ref = dy.float().t() @ x.float()
+    base = torch.randn(M, N, generator=torch.Generator().manual_seed(20))
+    dw = base.clone().cuda()
+    db = torch.full((M,), 0.5, device="cuda")
+    ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=True, split_k=split, bias_grad=db)
+    assert_close_bf16(dw, base + ref, ulps=0, name="split-k wgrad")
+    assert_close_bf16(db, 0.5 + dy.float().sum(0), ulps=0, name="fused bias grad")
+    dw2, db2 = base.clone().cuda(), torch.full((M,), 0.5, device="cuda")
+    ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw2, accumulate=True, split_k=split, bias_grad=db2)
+    assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed summation order: bit-reproducible
+    with pytest.raises(capi.SamHipError):          # split-K needs accumulate semantics
+        ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4)
+
+
 def test_strided_views_and_errors():
     ops, capi = _mods()
     big = rnd((300, 2304), 16).cuda()
