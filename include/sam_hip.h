@@ -80,6 +80,7 @@ typedef struct sam_gemm_desc {
                          accumulate=1, SAM_EPI_NONE.  Partials go to `ws` and are summed in a fixed order (bit-reproducible, no atomics). */
   float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] += sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad. */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
+  int32_t force_tile; /* 0: heuristic; 128 / 256: force the 128x128 (4-wave) or 256x256 (8-wave) block tile (testing, tuning) */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
 

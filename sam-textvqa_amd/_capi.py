@@ -18,7 +18,7 @@ class GemmDesc(C.Structure):
                 ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("bias", _vp), ("residual", _vp), ("ldr", _i64),
                 ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i64),
-                ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64)]
+                ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64), ("force_tile", C.c_int32)]
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)

@@ -15,7 +15,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BK = 64;
 
 struct GemmArgs {
   int M, N, K;
@@ -34,33 +34,36 @@ struct GemmArgs {
   float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
 };
 
-// ---- LDS images --------------------------------------------------------------------------------
-// k-contiguous operand: [128 rows][64 k] bf16, 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)
+// ---- LDS images (one 64-deep k-tile) -----------------------------------------------------------------
+// k-contiguous operand: [R rows][64 k] bf16, 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// k-strided operand: [64 k][128 cols] bf16, 256-byte rows, chunk c (8 cols) stored at c ^ ((k&7)<<1)
-__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * 256 + ((chunk ^ ((krow & 7) << 1)) << 4); }
+// k-strided operand: [64 k][C cols] bf16, 2C-byte rows, chunk c (8 cols) stored at c ^ ((k&7)<<1): the 8 k-rows that a
+// 32-lane ds_read_b64_tr_b16 group touches land on 8 distinct 32-byte bank ranges
+template <int C>
+__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * (2 * C) + ((chunk ^ ((krow & 7) << 1)) << 4); }
 
-template <bool KC>
-__device__ __forceinline__ void load_tile(uint4 (&r)[4], const bf16_t* base, int64_t ld, int row0, int rows, int k0, int K, int tid) {
+// predicated register-staged fill (partial last k-tile only). R = tile extent along the non-k index; NT threads.
+template <bool KC, int R, int NT>
+__device__ __forceinline__ void load_tile(uint4 (&r)[R * 8 / NT], const bf16_t* base, int64_t ld, int row0, int rows, int k0, int K, int tid) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = tid + 256 * j;
+  for (int j = 0; j < R * 8 / NT; ++j) {
+    const int c = tid + NT * j;
     r[j] = make_uint4(0, 0, 0, 0);
     if (KC) {
       const int row = row0 + (c >> 3), k = k0 + (c & 7) * 8;
       if (row < rows && k < K) r[j] = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + k);
     } else {
-      const int k = k0 + (c >> 4), col = row0 + (c & 15) * 8;
+      const int k = k0 + c / (R / 8), col = row0 + (c % (R / 8)) * 8;
       if (k < K && col < rows) r[j] = *reinterpret_cast<const uint4*>(base + (int64_t)k * ld + col);
     }
   }
 }
-template <bool KC>
-__device__ __forceinline__ void store_tile(unsigned char* lds, const uint4 (&r)[4], int tid) {
+template <bool KC, int R, int NT>
+__device__ __forceinline__ void store_tile(unsigned char* lds, const uint4 (&r)[R * 8 / NT], int tid) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = tid + 256 * j;
-    const int off = KC ? kc_off(c >> 3, c & 7) : ks_off(c >> 4, c & 15);
+  for (int j = 0; j < R * 8 / NT; ++j) {
+    const int c = tid + NT * j;
+    const int off = KC ? kc_off(c >> 3, c & 7) : ks_off<R>(c / (R / 8), c % (R / 8));
     *reinterpret_cast<uint4*>(lds + off) = r[j];
   }
 }
@@ -68,11 +71,12 @@ __device__ __forceinline__ void store_tile(unsigned char* lds, const uint4 (&r)[
 // direct-to-LDS tile fill.  One wave instruction writes 1 KB lane-linearly: lane l lands at byte 16*l of the slice, so
 // lane l must FETCH the chunk that the swizzled image keeps there.  Rows / columns past the matrix edge are clamped to
 // the last valid one: they only feed output rows/cols that are never stored.  K must cover the whole 64-wide tile.
-template <bool KC>
+template <bool KC, int R, int NWAVES>
 __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base, int64_t ld, int row0, int rows, int k0, int wave, int lane) {
+  constexpr int SLICES = R / 8;   // 1 KB slices in the 16*R-byte... (R rows x 128 B, or 64 k-rows x 2R B): both R*128 bytes
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int j = wave * 4 + jj;  // 1 KB slice index 0..15
+  for (int jj = 0; jj < SLICES / NWAVES; ++jj) {
+    const int j = wave * (SLICES / NWAVES) + jj;
     const bf16_t* src;
     if (KC) {
       const int row = 8 * j + (lane >> 3), pos = lane & 7;
@@ -80,7 +84,8 @@ __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base
       const int grow = min(row0 + row, rows - 1);
       src = base + (int64_t)grow * ld + k0 + c * 8;
     } else {
-      const int krow = 4 * j + (lane >> 4), pos = lane & 15;
+      const int byte = j * 1024 + lane * 16;
+      const int krow = byte / (2 * R), pos = (byte % (2 * R)) >> 4;
       const int cc = pos ^ ((krow & 7) << 1);
       const int col = min(row0 + cc * 8, rows - 8);
       src = base + (int64_t)(k0 + krow) * ld + col;
@@ -93,7 +98,7 @@ __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base
 // fragment of 16 rows (row0..row0+15 of the operand's M/N index) x 32 k (step ks) for lane (i,g).
 // NATURAL k map (both operands k-contiguous): k = 32ks + 8g + e.
 // SPLIT k map (any operand k-strided):        k = 32ks + 16(e>>2) + 4g + (e&3)   -- both operands must agree.
-template <bool KC, bool SPLIT>
+template <bool KC, bool SPLIT, int R>
 __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, int ks, int i, int g) {
   if (KC) {
     const int row = row0 + i;
@@ -104,8 +109,8 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, 
     return cat4(lo, hi);
   } else {
     const int krow = 32 * ks + 4 * g + (i >> 2);
-    const unsigned char* p = lds + ks_off(krow, (row0 >> 3) + ((i & 3) >> 1)) + (i & 1) * 8;
-    return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * 256));
+    const unsigned char* p = lds + ks_off<R>(krow, (row0 >> 3) + ((i & 3) >> 1)) + (i & 1) * 8;
+    return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * 2 * R));
   }
 }
 
@@ -118,21 +123,25 @@ template <> struct Store4<bf16_t> {
 template <> struct Store4<float> {
   // accumulate: 0 = store, 1 = read-modify-write (every element has exactly one writer)
   static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int accumulate) {
-    float* f = reinterpret_cast<float*>(C) + idx;
-    float4* p = reinterpret_cast<float4*>(f);
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx);
     float4 o = make_float4(v[0], v[1], v[2], v[3]);
     if (accumulate) { const float4 c = *p; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
     *p = o;
   }
 };
 
-template <bool AKC, bool BKC, int EPI, typename OutT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
-  constexpr int TILE_BYTES = BM * BK * 2;  // 16 KB per operand per stage
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];   // [stage][A|B]
+// Tile configuration: BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
+//   <128,128,2,2>: 256 threads, 64 KB LDS, 2 blocks/CU  -- 64 flop per byte staged
+//   <256,256,2,4>: 512 threads, 128 KB LDS, 1 block/CU  -- 128 flop per byte staged (opt-in via force_tile, see launch())
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmArgs p) {
+  constexpr int NT = 64 * WM * WN, NWAVES = WM * WN;
+  constexpr int TM = BM / WM / 16, TN = BN / WN / 16;      // 16x16 fragments per wave
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [stage][A|B]
   constexpr bool SPLIT = !(AKC && BKC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int wm = wave & 1, wn = wave >> 1;
+  const int wm = wave % WM, wn = wave / WM;
 
   // XCD-aware tile order: block b runs on XCD b%8; give each XCD a contiguous run of tiles (n fastest) so the
   // tiles that share an A panel / the whole B panel meet in one L2.
@@ -145,36 +154,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   }
   const int m0 = (bid / p.tiles_n) * BM, n0 = (bid % p.tiles_n) * BN;
 
-  f32x4 acc[4][4];
+  f32x4 acc[TN][TM];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < TN; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int KT_all = (p.K + BK - 1) / BK;
   const int per = (KT_all + p.split_k - 1) / p.split_k;
   const int kt_begin = split * per, KT = min(KT_all, kt_begin + per);
   if (kt_begin >= KT) return;   // whole block leaves together: no barrier has been reached
   const bool do_bias = !AKC && p.bias_grad != nullptr && n0 == 0 && wn == 0;
-  f32x4 accb[4];
+  f32x4 accb[TM];
 #pragma unroll
-  for (int a = 0; a < 4; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int a = 0; a < TM; ++a) accb[a] = f32x4{0.f, 0.f, 0.f, 0.f};
   const short one_bf16 = (short)0x3F80;
   const bf16x8 ones = {one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16, one_bf16};
 
-  const int KT_full = p.K / BK;   // k-tiles that are entirely inside K: direct-to-LDS; a partial last tile is register staged
+  const int KT_full = p.K / BK;   // k-tiles entirely inside K go direct-to-LDS; a partial last tile is register staged
   auto fill = [&](int kt, int stage) {
-    unsigned char* As_ = smem + stage * 2 * TILE_BYTES;
-    unsigned char* Bs_ = As_ + TILE_BYTES;
+    unsigned char* As_ = smem + stage * STAGE_BYTES;
+    unsigned char* Bs_ = As_ + A_BYTES;
     if (kt < KT_full) {
-      glds_tile<AKC>(As_, p.A, p.lda, m0, p.M, kt * BK, wave, lane);
-      glds_tile<BKC>(Bs_, p.B, p.ldb, n0, p.N, kt * BK, wave, lane);
+      glds_tile<AKC, BM, NWAVES>(As_, p.A, p.lda, m0, p.M, kt * BK, wave, lane);
+      glds_tile<BKC, BN, NWAVES>(Bs_, p.B, p.ldb, n0, p.N, kt * BK, wave, lane);
     } else {
-      uint4 ra[4], rb[4];
-      load_tile<AKC>(ra, p.A, p.lda, m0, p.M, kt * BK, p.K, tid);
-      load_tile<BKC>(rb, p.B, p.ldb, n0, p.N, kt * BK, p.K, tid);
-      store_tile<AKC>(As_, ra, tid);
-      store_tile<BKC>(Bs_, rb, tid);
+      uint4 ra[BM * 8 / NT], rb[BN * 8 / NT];
+      load_tile<AKC, BM, NT>(ra, p.A, p.lda, m0, p.M, kt * BK, p.K, tid);
+      load_tile<BKC, BN, NT>(rb, p.B, p.ldb, n0, p.N, kt * BK, p.K, tid);
+      store_tile<AKC, BM, NT>(As_, ra, tid);
+      store_tile<BKC, BN, NT>(Bs_, rb, tid);
     }
   };
   fill(kt_begin, 0);
@@ -182,24 +191,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
     const int stage = (kt - kt_begin) & 1;
     __syncthreads();   // tile kt has landed (the compiler drains vmcnt before the barrier) and everyone left stage^1
     if (kt + 1 < KT) fill(kt + 1, stage ^ 1);
-    const unsigned char* As = smem + stage * 2 * TILE_BYTES;
-    const unsigned char* Bs = As + TILE_BYTES;
+    const unsigned char* As = smem + stage * STAGE_BYTES;
+    const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 af[4], bf[4];
+      bf16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        af[t] = load_frag<AKC, SPLIT>(As, wm * 64 + t * 16, ks, i, g);
-        bf[t] = load_frag<BKC, SPLIT>(Bs, wn * 64 + t * 16, ks, i, g);
-      }
+      for (int t = 0; t < TM; ++t) af[t] = load_frag<AKC, SPLIT, BM>(As, wm * (BM / WM) + t * 16, ks, i, g);
 #pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
+      for (int t = 0; t < TN; ++t) bf[t] = load_frag<BKC, SPLIT, BN>(Bs, wn * (BN / WN) + t * 16, ks, i, g);
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm)
+      for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
           acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[tn], af[tm], acc[tn][tm], 0, 0, 0);
-      if (do_bias) {  // D[n][m] = sum_k 1 * A(m,k): every row n holds the column sums of this wave's 64 m
+      if (do_bias) {  // D[n][m] = sum_k 1 * A(m,k): every row n holds the column sums of this wave's m range
 #pragma unroll
-        for (int tm = 0; tm < 4; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[tm], accb[tm], 0, 0, 0);
+        for (int tm = 0; tm < TM; ++tm) accb[tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[tm], accb[tm], 0, 0, 0);
       }
     }
   }
@@ -207,8 +215,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   if (do_bias && g == 0) {   // each m has exactly one writer per split: no atomics
     float* bdst = p.split_k > 1 ? p.ws + (int64_t)p.split_k * p.M * p.N + (int64_t)split * p.M : p.bias_grad;
 #pragma unroll
-    for (int tm = 0; tm < 4; ++tm) {
-      const int m = m0 + wm * 64 + tm * 16 + i;
+    for (int tm = 0; tm < TM; ++tm) {
+      const int m = m0 + wm * (BM / WM) + tm * 16 + i;
       if (m < p.M) bdst[m] = p.split_k > 1 ? accb[tm][0] : bdst[m] + accb[tm][0];
     }
   }
@@ -216,14 +224,14 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs p) {
   int64_t ldc = p.ldc;
   int accumulate = p.accumulate;
   if (p.split_k > 1) { Cout = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; accumulate = 0; }
-  // epilogue: lane owns rows m = m0 + wm*64 + tm*16 + i, columns n = n0 + wn*64 + tn*16 + 4g .. +3
+  // epilogue: lane owns rows m = m0 + wm*(BM/WM) + tm*16 + i, columns n = n0 + wn*(BN/WN) + tn*16 + 4g .. +3
 #pragma unroll
-  for (int tm = 0; tm < 4; ++tm) {
-    const int m = m0 + wm * 64 + tm * 16 + i;
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm * (BM / WM) + tm * 16 + i;
     if (m >= p.M) continue;
 #pragma unroll
-    for (int tn = 0; tn < 4; ++tn) {
-      const int n = n0 + wn * 64 + tn * 16 + 4 * g;
+    for (int tn = 0; tn < TN; ++tn) {
+      const int n = n0 + wn * (BN / WN) + tn * 16 + 4 * g;
       if (n >= p.N) continue;
       float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
       if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES) {
@@ -285,15 +293,54 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
   }
 }
 
-template <bool AKC, bool BKC, int EPI, typename OutT>
-int launch(const GemmArgs& a, hipStream_t st) {
-  gemm_kernel<AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(256), 0, st>>>(a);
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+int launch_cfg(GemmArgs a, hipStream_t st) {
+  constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    once = true;
+  }
+  gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(64 * WM * WN), LDS, st>>>(a);
   if (a.split_k > 1) {
     const int64_t mn4 = (int64_t)a.M * a.N / 4;
     splitk_reduce_kernel<<<dim3((unsigned)min((int64_t)2048, (mn4 + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.split_k, a.M, a.N, (float*)a.C, a.ldc, a.bias_grad);
   }
   SAM_LAUNCH_CHECK();
   return SAM_OK;
+}
+
+// split-K factor for a given tile count: enough workgroups to give every CU `per_cu` of them, >= 4 k-tiles per split
+int pick_split(int requested, int tiles, int kt, int per_cu, int64_t per_split_bytes, int64_t ws_bytes) {
+  int s = requested;
+  if (s < 0) {
+    s = (256 * per_cu + tiles - 1) / tiles;
+    if (s > kt / 4) s = kt / 4;
+    if (s > 32) s = 32;
+  }
+  if (s > kt) s = kt;
+  if (per_split_bytes > 0 && (int64_t)s * per_split_bytes > ws_bytes) s = (int)(ws_bytes / per_split_bytes);
+  return s < 1 ? 1 : s;
+}
+
+template <bool AKC, bool BKC, int EPI, typename OutT>
+int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int force_tile) {
+  const int kt = (a.K + BK - 1) / BK;
+  const int64_t per_split = ((int64_t)a.M * a.N + a.M) * (int64_t)sizeof(float);
+  const int tm_big = (a.M + 255) / 256, tn_big = (a.N + 255) / 256;
+  // The 256x256 / 8-wave configuration is parity-tested but NOT selected by default: with this simple one-barrier-per-k-tile
+  // loop it measures equal or slower than 128x128 on every shape of the SA-M4C step at M = 11648 (tools/bench_gemm.py:
+  // e.g. fwd N=3072 650 vs 723 TFLOP/s, wgrad 3072x768 412 vs 548) -- one resident block per CU stalls all 8 waves on
+  // each DMA wait, and 46 x N/256 tiles quantise badly over 256 CUs.  It needs a phase-staggered loop to pay off.
+  bool big = force_tile == 256;
+  if (big) {
+    a.tiles_m = tm_big; a.tiles_n = tn_big;
+    if (want_split != 0) a.split_k = pick_split(want_split, tm_big * tn_big, kt, 1, per_split, ws_bytes);
+    return launch_cfg<256, 256, 2, 4, AKC, BKC, EPI, OutT>(a, st);
+  }
+  a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
+  if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 3, per_split, ws_bytes);
+  return launch_cfg<128, 128, 2, 2, AKC, BKC, EPI, OutT>(a, st);
 }
 
 }  // namespace
@@ -318,28 +365,21 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.thr16 = dropout_thr16(d->p_drop);
   a.inv_keep = a.thr16 ? 1.0f / (1.0f - (float)a.thr16 / 65536.0f) : 1.0f;
   a.seed_lo = (unsigned)d->seed; a.seed_hi = (unsigned)(d->seed >> 32); a.off_lo = (unsigned)d->offset; a.off_hi = (unsigned)(d->offset >> 32);
-  a.tiles_m = (d->M + BM - 1) / BM; a.tiles_n = (d->N + BN - 1) / BN;
   a.split_k = 1;
   a.bias_grad = d->bias_grad;
+  a.ws = d->ws;
   SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
-  if (d->split_k != 0 && d->split_k != 1) {
+  int want_split = (d->split_k == 1) ? 0 : d->split_k;
+  if (want_split != 0) {
     SAM_REQUIRE(d->c_is_f32 && d->epilogue == SAM_EPI_NONE && d->accumulate, "sam_gemm_bf16: split_k needs an fp32 C with accumulate=1 and no epilogue");
     SAM_REQUIRE(d->ws && ((uintptr_t)d->ws % 16 == 0), "sam_gemm_bf16: split_k needs a 16-byte aligned workspace");
-    const int kt = (d->K + BK - 1) / BK, tiles = a.tiles_m * a.tiles_n;
     const int64_t per_split = ((int64_t)d->M * d->N + d->M) * (int64_t)sizeof(float);
-    int s = d->split_k;
-    if (s < 0) {  // auto: ~3 workgroups per CU, at least 4 k-tiles per split
-      s = (768 + tiles - 1) / tiles;
-      if (s > kt / 4) s = kt / 4;
-      if (s > 32) s = 32;
-    }
-    if (s > kt) s = kt;
-    if ((int64_t)s * per_split > d->ws_bytes) s = (int)(d->ws_bytes / per_split);
-    SAM_REQUIRE(d->split_k < 0 || s == d->split_k || s >= kt, "sam_gemm_bf16: workspace too small for split_k=%d (%lld bytes)", d->split_k, (long long)d->ws_bytes);
-    if (s < 1) s = 1;
-    a.split_k = s;
-    a.ws = d->ws;
+    SAM_REQUIRE(want_split < 0 || (int64_t)want_split * per_split <= d->ws_bytes || want_split > (d->K + BK - 1) / BK,
+                "sam_gemm_bf16: workspace too small for split_k=%d (%lld bytes)", d->split_k, (long long)d->ws_bytes);
   }
+  const int64_t wsb = d->ws_bytes;
+  const int ft = d->force_tile;
+  SAM_REQUIRE(ft == 0 || ft == 128 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 128 or 256");
   hipStream_t st = (hipStream_t)stream;
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
@@ -348,23 +388,23 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   if (e == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T
     if (d->c_is_f32) {
-      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, float>(a, st);
-      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, float>(a, st);
+      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, float>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, float>(a, st, want_split, wsb, ft);
     } else {
-      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, bf16_t>(a, st);
-      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, bf16_t>(a, st);
-      if (e == SAM_EPI_BIAS_GELU) return launch<true, true, SAM_EPI_BIAS_GELU, bf16_t>(a, st);
-      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, true, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st);
+      if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS_GELU) return launch<true, true, SAM_EPI_BIAS_GELU, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, true, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st, want_split, wsb, ft);
     }
   } else if (lay == 2) {  // dgrad: dy[M,N'] . W[N',K']
     if (!d->c_is_f32) {
-      if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, bf16_t>(a, st);
-      if (e == SAM_EPI_DGELU) return launch<true, false, SAM_EPI_DGELU, bf16_t>(a, st);
-      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, false, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st);
-    } else if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, float>(a, st);
+      if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_DGELU) return launch<true, false, SAM_EPI_DGELU, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, false, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st, want_split, wsb, ft);
+    } else if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, float>(a, st, want_split, wsb, ft);
   } else if (lay == 0) {  // wgrad: dy[rows,M]^T . x[rows,N]
-    if (d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, float>(a, st);
-    if (!d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, bf16_t>(a, st);
+    if (d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, float>(a, st, want_split, wsb, ft);
+    if (!d->c_is_f32 && e == SAM_EPI_NONE) return launch<false, false, SAM_EPI_NONE, bf16_t>(a, st, want_split, wsb, ft);
   }
   sam_set_error("sam_gemm_bf16: no kernel for layout (a_kcontig=%d,b_kcontig=%d) epilogue=%d c_is_f32=%d", d->a_kcontig, d->b_kcontig, e, d->c_is_f32);
   return SAM_ERR_UNSUPPORTED;

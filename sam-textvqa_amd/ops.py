@@ -109,7 +109,7 @@ def _dp(t):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=None, out_dtype=BF16, epilogue=capi.EPI_NONE,
-         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0, split_k=0, bias_grad=None):
+         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0, split_k=0, bias_grad=None, force_tile=0):
     """C[M,N] = epilogue(sum_k A(m,k) B(k,n)); see include/sam_hip.h `sam_gemm_bf16` for layouts and epilogues.
     a, b: 2-D bf16 tensors whose LAST dim is contiguous (row stride = leading dimension)."""
     for t, nm in ((a, "A"), (b, "B")):
@@ -131,7 +131,7 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     aux = aux_out if aux_out is not None else aux_in
     d.ld_aux = aux.stride(0) if aux is not None else 0
     d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
-    d.split_k, d.bias_grad = int(split_k), _dp(bias_grad)
+    d.split_k, d.bias_grad, d.force_tile = int(split_k), _dp(bias_grad), int(force_tile)
     if split_k not in (0, 1):
         want = split_k if split_k > 0 else 32
         ws = _workspace(min(want * (M * N + M) * 4, 96 << 20), a.device, "splitk")

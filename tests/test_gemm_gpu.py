@@ -121,6 +121,22 @@ def test_wgrad_split_k_and_fused_bias_grad(R, M, N, split):
         ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4)
 
 
+@pytest.mark.parametrize("tile", [128, 256])
+def test_both_tile_configs_all_layouts(tile):
+    ops, capi = _mods()
+    M, N, K = 600, 520, 712          # ragged in every dimension for both tile sizes; K % 64 != 0
+    x, w, b = rnd((M, K), 21), rnd((N, K), 22, 0.05), torch.randn(N, generator=torch.Generator().manual_seed(23))
+    assert_close_bf16(ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS, bias=b.cuda(), force_tile=tile), x.float() @ w.float().t() + b, name="fwd")
+    dy, w2 = rnd((M, K), 24), rnd((K, N), 25, 0.05)
+    assert_close_bf16(ops.gemm(dy.cuda(), w2.cuda(), b_kcontig=False, force_tile=tile), dy.float() @ w2.float(), name="dgrad")
+    R = 1000
+    dyy, xx = rnd((R, 520), 26), rnd((R, 264), 27)
+    dw, db = torch.zeros(520, 264, device="cuda"), torch.zeros(520, device="cuda")
+    ops.gemm(dyy.cuda(), xx.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=True, split_k=-1, bias_grad=db, force_tile=tile)
+    assert_close_bf16(dw, dyy.float().t() @ xx.float(), ulps=0, name="wgrad")
+    assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
+
+
 def test_strided_views_and_errors():
     ops, capi = _mods()
     big = rnd((300, 2304), 16).cuda()

@@ -15,12 +15,12 @@ def rnd(*s): return torch.randn(*s, device="cuda").to(torch.bfloat16)
 rows = []
 for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
     x, w = rnd(R, K), rnd(N, K)
-    us = t(lambda: ops.gemm(x, w)); rows.append(("fwd  M=%d N=%d K=%d" % (R, N, K), us, 2.0 * R * N * K))
     dy = rnd(R, N)
-    us = t(lambda: ops.gemm(dy, w, b_kcontig=False)); rows.append(("dgrad M=%d N=%d K=%d" % (R, K, N), us, 2.0 * R * N * K))
     out = torch.zeros(N, K, device="cuda")
-    for sk in (0, 2, 4, 8, -1):
-        us = t(lambda: ops.gemm(dy, x, a_kcontig=False, b_kcontig=False, out=out, accumulate=True, split_k=sk))
-        rows.append(("wgrad out=%dx%d rows=%d split=%d" % (N, K, R, sk), us, 2.0 * R * N * K))
+    for ft in (128, 256):
+        us = t(lambda: ops.gemm(x, w, force_tile=ft)); rows.append(("fwd  M=%d N=%d K=%d tile=%d" % (R, N, K, ft), us, 2.0 * R * N * K))
+        us = t(lambda: ops.gemm(dy, w, b_kcontig=False, force_tile=ft)); rows.append(("dgrad M=%d N=%d K=%d tile=%d" % (R, K, N, ft), us, 2.0 * R * N * K))
+        us = t(lambda: ops.gemm(dy, x, a_kcontig=False, b_kcontig=False, out=out, accumulate=True, split_k=-1, force_tile=ft))
+        rows.append(("wgrad out=%dx%d rows=%d split=auto tile=%d" % (N, K, R, ft), us, 2.0 * R * N * K))
 for name, us, fl in rows:
     print("%-44s %8.1f us  %7.1f TFLOP/s" % (name, us, fl / us / 1e6))
