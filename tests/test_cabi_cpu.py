@@ -1,0 +1,81 @@
+"""CPU (no GPU needed): the C-ABI library builds, loads, and exports every symbol include/sam_hip.h declares; the
+ctypes signatures cover the header; and the product path refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "sam_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sam_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    import sam_textvqa_amd._build as b
+    lib_path = b.build()
+    assert os.path.exists(lib_path)
+    lib = ctypes.CDLL(lib_path)
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libsam_hip.so does not export %s declared in include/sam_hip.h" % n
+
+
+def test_ctypes_binding_covers_the_header():
+    from sam_textvqa_amd import _capi
+    declared = set(header_functions()) - {"sam_last_error", "sam_device_info", "sam_gemm_desc"}
+    bound = set(_capi.SIGNATURES)
+    assert declared <= bound, "unbound entry points: %s" % sorted(declared - bound)
+    assert bound <= set(header_functions()), "bound but undeclared: %s" % sorted(bound - set(header_functions()))
+    l = _capi.lib()
+    assert l.sam_abi_version() == 1
+    assert _capi.call("sam_attn_words_per_row", 182) == 6 and _capi.call("sam_attn_words_per_row", 20) == 1
+    assert _capi.call("sam_attn_words_per_row", 350) == 12 and _capi.call("sam_attn_words_per_row", 385) == -1
+
+
+def test_gemm_desc_layout_matches_header_field_order():
+    from sam_textvqa_amd import _capi
+    src = open(os.path.join(ROOT, "include", "sam_hip.h")).read()
+    body = re.sub(r"/\*.*?\*/", "", src[src.index("typedef struct sam_gemm_desc {"): src.index("} sam_gemm_desc;")], flags=re.S)
+    fields = re.findall(r"\b\*?\s*([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", body)
+    assert fields == [f[0] for f in _capi.GemmDesc._fields_], fields
+
+
+def test_argument_errors_are_reported_without_a_gpu():
+    """argument validation happens before any launch, so it can be exercised on a CPU-only box"""
+    from sam_textvqa_amd import _capi
+    with pytest.raises(_capi.SamHipError) as e:
+        _capi.call("sam_attn_fwd", None, None, 0, 0, 1, 8, 12, 32, 0.1, 0.0, 0, 0, None, None, None, None)
+    assert "head_dim" in str(e.value)
+    d = _capi.GemmDesc()
+    with pytest.raises(_capi.SamHipError):
+        _capi.call("sam_gemm_bf16", d, None)          # empty problem
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only check")
+def test_product_path_fails_loudly_without_gpu():
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd import ops
+    from sam_textvqa_amd._capi import SamHipError
+    with pytest.raises(SamHipError):
+        ops.mask_bits_prefix_lm(torch.ones(2, 8, dtype=torch.uint8), 2)       # CPU tensor: rejected, no fallback
+    cfg = M.BertConfig.from_dict(dict(hidden_size=768, num_spatial_relations=12, max_seq_length=4, num_decoding_steps=2,
+                                      attention_mask_quadrants=[1, 2], intermediate_size=64))
+    layer = M.SpatialBertLayer(cfg)
+    with pytest.raises(Exception):
+        layer(torch.zeros(1, 10, 768), torch.zeros(1, 1, 10, 10), torch.zeros(1, 4, 4, 12, dtype=torch.int8))
+
+
+def test_no_oracle_import_in_product_package():
+    pkg = os.path.join(ROOT, "sam-textvqa_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, "%s imports the oracle" % f

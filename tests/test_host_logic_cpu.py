@@ -1,0 +1,87 @@
+"""CPU: host-side logic of the product package that needs no kernels — config objects, module surface / state_dict keys,
+LR schedule, synthetic batch schema, reducer bucket planning."""
+import torch
+
+from oracle import sa_m4c_oracle as O
+from tests import oracle_cases as OC
+
+
+def test_config_from_dict_copies_every_key():
+    import sam_textvqa_amd.modules as M
+    c = M.BertConfig.from_dict(dict(hidden_size=96, layer_type_list=["n", "s"], mix_list=["none", "share3"], foo=1))
+    assert c.hidden_size == 96 and c.layer_type_list == ["n", "s"] and c.foo == 1 and c.layer_norm_eps == 1e-12
+    assert c.attention_probs_dropout_prob == 0.1 and c.intermediate_size == 3072
+
+
+def test_module_surface_and_state_dict_keys_equal_oracle():
+    import sam_textvqa_amd.modules as M
+    mcfg, tcfg = OC.sam4c_configs("sam4c_small_c3")
+    kw = dict(mcfg.__dict__, hidden_size=768, intermediate_size=128, ptr_query_size=768)
+    model = M.SAM4C(M.BertConfig.from_dict(kw), M.BertConfig.from_dict(tcfg.__dict__), num_answers=30, bos_idx=1)
+    ref = O.SAM4C(O.BertConfig.from_dict(kw), O.BertConfig.from_dict(tcfg.__dict__), num_answers=30)
+    assert list(model.state_dict()) == list(ref.state_dict())
+    for k, v in ref.state_dict().items():
+        assert model.state_dict()[k].shape == v.shape, k
+    model.load_state_dict(ref.state_dict())                       # a reference-layout checkpoint is a drop-in
+    groups = model.get_optimizer_parameters(1e-4)
+    assert [len(g["params"]) for g in groups] == [len(g["params"]) for g in ref.get_optimizer_parameters(1e-4)]
+    assert "lr" not in groups[0] and groups[1]["lr"] == 1e-4
+    for name in ("SpatialBertSelfAttention", "SpatialBertAttention", "SpatialBertLayer", "BertSpatialEncoder", "MMT", "OcrPtrNet",
+                 "PrevPredEmbeddings", "TextBert", "BertLayerNorm", "SAM4C"):
+        assert hasattr(M, name)
+
+
+def test_unsupported_options_raise():
+    import pytest
+    import sam_textvqa_amd.modules as M
+    base = dict(hidden_size=768, num_spatial_relations=12, max_seq_length=4, num_decoding_steps=2, attention_mask_quadrants=[1, 2])
+    with pytest.raises(NotImplementedError):
+        M.SpatialBertSelfAttention(M.BertConfig.from_dict(dict(base, use_bias=True)))
+    with pytest.raises(ValueError):
+        M.SpatialBertSelfAttention(M.BertConfig.from_dict(dict(base, hidden_size=100)))
+    with pytest.raises(NotImplementedError):
+        M.BertIntermediate(M.BertConfig.from_dict(dict(base, hidden_act="relu")))
+
+
+def test_lr_schedule_matches_oracle():
+    from sam_textvqa_amd.trainer import lr_lambda
+    for it in (0, 1, 500, 1000, 1001, 13999, 14000, 18999, 19000, 50000):
+        assert lr_lambda(it) == O.lr_lambda(it)
+    assert lr_lambda(10, warmup_iters=20, warmup_factor=0.5) == 0.75
+
+
+def test_synthetic_batch_schema_cpu():
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    bd = make_batch(3, vocab=100, device="cpu", seed=7)
+    shapes = {"pad_obj_features": (3, 100, 2048), "pad_obj_bboxes": (3, 100, 5), "pad_ocr_bboxes": (3, 50, 5), "pad_obj_mask": (3, 100),
+              "pad_ocr_mask": (3, 50), "pad_ocr_features": (3, 50, 2048), "ocr_fasttext": (3, 50, 300), "ocr_phoc": (3, 50, 604),
+              "question_indices": (3, 20), "question_mask": (3, 20), "train_prev_inds": (3, 12), "targets": (3, 12, 150), "train_loss_mask": (3, 12)}
+    for k, s in shapes.items():
+        assert tuple(bd[k].shape) == s, k
+    adj = bd["spatial_adj_matrices"]["3"]
+    assert adj.dtype == torch.int8 and tuple(adj.shape) == (3, 150, 150, 12)
+    assert bd["pad_obj_mask"].dtype == torch.long and bd["train_prev_inds"].dtype == torch.long and (bd["train_prev_inds"][:, 0] == 1).all()
+    # padded OCR boxes are all-zero and carry no relations; valid diagonal = relation 12
+    n_ocr = bd["pad_ocr_mask"].sum(1)
+    for b in range(3):
+        assert (adj[b, 100 + n_ocr[b]:, :, :] == 0).all() and (adj[b, :, 100 + n_ocr[b]:, :] == 0).all()
+        assert (adj[b, torch.arange(100), torch.arange(100), 11] == 1).all()
+    # the oracle runs on it (same schema as the reference's batch_dict)
+    c2 = clone_batch(bd)
+    assert c2 is not bd and c2["targets"] is bd["targets"]
+    dens = adj[:, :100, :100, 3:11].float().mean().item()
+    assert 0.2 < dens < 0.45, dens           # c=3: ~1/3 of valid pairs on each sector head
+
+
+def test_reducer_bucket_plan_and_region_order():
+    from sam_textvqa_amd.parallel import GradReducer
+    g = torch.zeros(1000)
+    red = GradReducer(g, bucket_bytes=4 * 256)
+    assert red.buckets == [(744, 1000), (488, 744), (232, 488), (0, 232)]
+    ids = red.register_regions([(100, 300), (300, 600), (600, 1000)])      # layers in address order
+    assert ids == [2, 1, 0]
+    red.mark_done(ids[0])                      # lowest layer finishing first releases nothing
+    assert red.next_bucket == 0
+    red.mark_done(ids[2]); assert red.next_bucket == 1          # [744,1000) complete
+    red.mark_done(ids[1]); assert red.next_bucket == 3          # everything >= 100 final -> buckets down to lo >= 100
+    red.finish(); assert red.next_bucket == 4
