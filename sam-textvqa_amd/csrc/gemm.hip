@@ -37,10 +37,11 @@ struct GemmArgs {
 // ---- LDS images (one 64-deep k-tile) -----------------------------------------------------------------
 // k-contiguous operand: [R rows][64 k] bf16, 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)
 __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
-// k-strided operand: [64 k][C cols] bf16, 2C-byte rows, chunk c (8 cols) stored at c ^ ((k&7)<<1): the 8 k-rows that a
-// 32-lane ds_read_b64_tr_b16 group touches land on 8 distinct 32-byte bank ranges
+// k-strided operand: [64 k][C cols] bf16, 2C-byte rows, chunk c (8 cols) stored at c ^ (S(k)<<1), S(k) = k&3 | ((k>>3)&1)<<2:
+// a 32-lane ds_read_b64_tr_b16 group reads the 8 k-rows {8g..8g+3, 8(g+1)..8(g+1)+3}; S makes them 8 distinct 32-byte bank ranges
+__device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
 template <int C>
-__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * (2 * C) + ((chunk ^ ((krow & 7) << 1)) << 4); }
+__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * (2 * C) + ((chunk ^ ks_swz(krow)) << 4); }
 
 // predicated register-staged fill (partial last k-tile only). R = tile extent along the non-k index; NT threads.
 template <bool KC, int R, int NT>
@@ -86,7 +87,7 @@ __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base
     } else {
       const int byte = j * 1024 + lane * 16;
       const int krow = byte / (2 * R), pos = (byte % (2 * R)) >> 4;
-      const int cc = pos ^ ((krow & 7) << 1);
+      const int cc = pos ^ ks_swz(krow);
       const int col = min(row0 + cc * 8, rows - 8);
       src = base + (int64_t)(k0 + krow) * ld + col;
     }
@@ -95,22 +96,19 @@ __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base
   }
 }
 
-// fragment of 16 rows (row0..row0+15 of the operand's M/N index) x 32 k (step ks) for lane (i,g).
-// NATURAL k map (both operands k-contiguous): k = 32ks + 8g + e.
-// SPLIT k map (any operand k-strided):        k = 32ks + 16(e>>2) + 4g + (e&3)   -- both operands must agree.
-template <bool KC, bool SPLIT, int R>
+// fragment of 16 rows (row0..row0+15 of the operand's M/N index) x 32 k (step ks) for lane (i,g): k = 32ks + 8g + e for BOTH
+// storage kinds, so any pairing of operands agrees on the contraction order.  k-contiguous: one ds_read_b128; k-strided: two
+// ds_read_b64_tr_b16 (k-rows 8g..8g+3 and 8g+4..8g+7; S(k+4) = S(k) for those rows, so the second read is a fixed offset).
+// (An earlier version used a split k map with two ds_read_b64 on the k-contiguous side: the compiler fused them into
+// ds_read2_b64, whose 32-bank rule gave 40% LDS conflict cycles in dgrad - SQ_LDS_BANK_CONFLICT/SQ_LDS_IDX_ACTIVE.)
+template <bool KC, int R>
 __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, int ks, int i, int g) {
   if (KC) {
-    const int row = row0 + i;
-    if (!SPLIT) return *reinterpret_cast<const bf16x8*>(lds + kc_off(row, 4 * ks + g));
-    const int c0 = 4 * ks + (g >> 1), w = (g & 1) * 8;
-    const s16x4 lo = *reinterpret_cast<const s16x4*>(lds + kc_off(row, c0) + w);
-    const s16x4 hi = *reinterpret_cast<const s16x4*>(lds + kc_off(row, c0 + 2) + w);
-    return cat4(lo, hi);
+    return *reinterpret_cast<const bf16x8*>(lds + kc_off(row0 + i, 4 * ks + g));
   } else {
-    const int krow = 32 * ks + 4 * g + (i >> 2);
+    const int krow = 32 * ks + 8 * g + (i >> 2);
     const unsigned char* p = lds + ks_off<R>(krow, (row0 >> 3) + ((i & 3) >> 1)) + (i & 1) * 8;
-    return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * 2 * R));
+    return cat4(lds_read_tr16(p), lds_read_tr16(p + 4 * 2 * R));
   }
 }
 
@@ -134,12 +132,13 @@ template <> struct Store4<float> {
 //   <128,128,2,2>: 256 threads, 64 KB LDS, 2 blocks/CU  -- 64 flop per byte staged
 //   <256,256,2,4>: 512 threads, 128 KB LDS, 1 block/CU  -- 128 flop per byte staged (opt-in via force_tile, see launch())
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   // 2 waves per SIMD = two 4-wave blocks (or one 8-wave block) per CU
   constexpr int NT = 64 * WM * WN, NWAVES = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;      // 16x16 fragments per wave
+  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "tile/wave shape");
+  static_assert(AKC || (BM & (BM - 1)) == 0, "k-strided A tiles need a power-of-two BM (XOR swizzle range)");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [stage][A|B]
-  constexpr bool SPLIT = !(AKC && BKC);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   const int wm = wave % WM, wn = wave / WM;
 
@@ -197,9 +196,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(GemmArgs p) {
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[TM], bf[TN];
 #pragma unroll
-      for (int t = 0; t < TM; ++t) af[t] = load_frag<AKC, SPLIT, BM>(As, wm * (BM / WM) + t * 16, ks, i, g);
+      for (int t = 0; t < TM; ++t) af[t] = load_frag<AKC, BM>(As, wm * (BM / WM) + t * 16, ks, i, g);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) bf[t] = load_frag<BKC, SPLIT, BN>(Bs, wn * (BN / WN) + t * 16, ks, i, g);
+      for (int t = 0; t < TN; ++t) bf[t] = load_frag<BKC, BN>(Bs, wn * (BN / WN) + t * 16, ks, i, g);
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -310,11 +309,12 @@ int launch_cfg(GemmArgs a, hipStream_t st) {
   return SAM_OK;
 }
 
-// split-K factor for a given tile count: enough workgroups to give every CU `per_cu` of them, >= 4 k-tiles per split
+// split-K factor for a given tile count: fill the `per_cu` x 256 resident block slots exactly ONCE (tiles x S just above a
+// multiple of the slot count costs a whole extra round: measured 91 us at S=3 vs 123 us at S=4 for 144 tiles), >= 4 k-tiles per split
 int pick_split(int requested, int tiles, int kt, int per_cu, int64_t per_split_bytes, int64_t ws_bytes) {
   int s = requested;
   if (s < 0) {
-    s = (256 * per_cu + tiles - 1) / tiles;
+    s = (256 * per_cu) / tiles;
     if (s > kt / 4) s = kt / 4;
     if (s > 32) s = 32;
   }
@@ -323,23 +323,37 @@ int pick_split(int requested, int tiles, int kt, int per_cu, int64_t per_split_b
   return s < 1 ? 1 : s;
 }
 
+// Block-tile choice.  Two 128x128 blocks fit a CU (LDS), i.e. 512 concurrent tiles; a grid of 546 tiles (M=11648, N=768, the
+// O-projection / FFN2 / two dgrads of every layer) then runs as one full round plus a nearly empty one.  Taller tiles
+// (BM = 160, 192; still 2 blocks per CU) trade a little per-tile time for a whole round: pick the BM that minimises
+// rounds(BM) x BM.  Only the k-contiguous-A layouts (forward, dgrad) need it; wgrad tops its grid up with split-K instead.
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int force_tile) {
   const int kt = (a.K + BK - 1) / BK;
   const int64_t per_split = ((int64_t)a.M * a.N + a.M) * (int64_t)sizeof(float);
-  const int tm_big = (a.M + 255) / 256, tn_big = (a.N + 255) / 256;
-  // The 256x256 / 8-wave configuration is parity-tested but NOT selected by default: with this simple one-barrier-per-k-tile
-  // loop it measures equal or slower than 128x128 on every shape of the SA-M4C step at M = 11648 (tools/bench_gemm.py:
-  // e.g. fwd N=3072 650 vs 723 TFLOP/s, wgrad 3072x768 412 vs 548) -- one resident block per CU stalls all 8 waves on
-  // each DMA wait, and 46 x N/256 tiles quantise badly over 256 CUs.  It needs a phase-staggered loop to pay off.
-  bool big = force_tile == 256;
-  if (big) {
-    a.tiles_m = tm_big; a.tiles_n = tn_big;
-    if (want_split != 0) a.split_k = pick_split(want_split, tm_big * tn_big, kt, 1, per_split, ws_bytes);
+  const int tn = (a.N + 127) / 128;
+  if (force_tile == 256) {
+    a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 255) / 256;
+    if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 1, per_split, ws_bytes);
     return launch_cfg<256, 256, 2, 4, AKC, BKC, EPI, OutT>(a, st);
   }
-  a.tiles_m = (a.M + 127) / 128; a.tiles_n = (a.N + 127) / 128;
-  if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 3, per_split, ws_bytes);
+  int bm = 128;
+  if constexpr (AKC) {
+    if (force_tile == 0 && want_split == 0) {
+      int64_t best = -1;
+      for (int cand : {128, 160, 192}) {
+        const int64_t tiles = (int64_t)((a.M + cand - 1) / cand) * tn;
+        const int64_t cost = ((tiles + 511) / 512) * (cand + 128) * 16 + (cand - 128);   // rounds x per-tile ingest (A+B rows), ties -> smaller
+        if (best < 0 || cost < best) { best = cost; bm = cand; }
+      }
+    } else if (force_tile == 160 || force_tile == 192) bm = force_tile;
+  }
+  a.tiles_m = (a.M + bm - 1) / bm; a.tiles_n = tn;
+  if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 2, per_split, ws_bytes);
+  if constexpr (AKC) {
+    if (bm == 160) return launch_cfg<160, 128, 2, 2, AKC, BKC, EPI, OutT>(a, st);
+    if (bm == 192) return launch_cfg<192, 128, 2, 2, AKC, BKC, EPI, OutT>(a, st);
+  }
   return launch_cfg<128, 128, 2, 2, AKC, BKC, EPI, OutT>(a, st);
 }
 
@@ -379,7 +393,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 128 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 128 or 256");
+  SAM_REQUIRE(ft == 0 || ft == 128 || ft == 160 || ft == 192 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 128, 160, 192 or 256");
   hipStream_t st = (hipStream_t)stream;
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;

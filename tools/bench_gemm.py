@@ -1,6 +1,6 @@
 """micro-benchmark of sam_gemm_bf16 over the shapes of one SA-M4C step (B=64 -> 11648 rows)"""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sam_textvqa_amd import ops, _capi as capi
 R = 11648
 def t(fn, n=20):
@@ -17,10 +17,14 @@ for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
     x, w = rnd(R, K), rnd(N, K)
     dy = rnd(R, N)
     out = torch.zeros(N, K, device="cuda")
-    for ft in (128, 256):
+    for ft in (128, 160, 192, 0):
         us = t(lambda: ops.gemm(x, w, force_tile=ft)); rows.append(("fwd  M=%d N=%d K=%d tile=%d" % (R, N, K, ft), us, 2.0 * R * N * K))
         us = t(lambda: ops.gemm(dy, w, b_kcontig=False, force_tile=ft)); rows.append(("dgrad M=%d N=%d K=%d tile=%d" % (R, K, N, ft), us, 2.0 * R * N * K))
-        us = t(lambda: ops.gemm(dy, x, a_kcontig=False, b_kcontig=False, out=out, accumulate=True, split_k=-1, force_tile=ft))
-        rows.append(("wgrad out=%dx%d rows=%d split=auto tile=%d" % (N, K, R, ft), us, 2.0 * R * N * K))
+    for sk in (-1, 3, 4, 5, 6, 8, 12, 14):
+        try:
+            us = t(lambda: ops.gemm(dy, x, a_kcontig=False, b_kcontig=False, out=out, accumulate=True, split_k=sk))
+            rows.append(("wgrad out=%dx%d rows=%d split=%d" % (N, K, R, sk), us, 2.0 * R * N * K))
+        except Exception as e:
+            pass
 for name, us, fl in rows:
     print("%-44s %8.1f us  %7.1f TFLOP/s" % (name, us, fl / us / 1e6))
