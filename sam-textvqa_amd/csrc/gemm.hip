@@ -40,8 +40,9 @@ __device__ __forceinline__ int kc_off(int row, int chunk) { return row * 128 + (
 // k-strided operand: [64 k][C cols] bf16, 2C-byte rows, chunk c (8 cols) stored at c ^ (S(k)<<1), S(k) = k&3 | ((k>>3)&1)<<2:
 // a 32-lane ds_read_b64_tr_b16 group reads the 8 k-rows {8g..8g+3, 8(g+1)..8(g+1)+3}; S makes them 8 distinct 32-byte bank ranges
 __device__ __forceinline__ int ks_swz(int krow) { return ((krow & 3) | (((krow >> 3) & 1) << 2)) << 1; }
+// (for C = 64 only 8 chunks exist per row: the XOR is masked to stay inside the row, leaving a 2-way conflict on that small-tile config)
 template <int C>
-__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * (2 * C) + ((chunk ^ ks_swz(krow)) << 4); }
+__device__ __forceinline__ int ks_off(int krow, int chunk) { return krow * (2 * C) + ((chunk ^ (ks_swz(krow) & (C / 8 - 1))) << 4); }
 
 // predicated register-staged fill (partial last k-tile only). R = tile extent along the non-k index; NT threads.
 template <bool KC, int R, int NT>
@@ -87,7 +88,7 @@ __device__ __forceinline__ void glds_tile(unsigned char* lds, const bf16_t* base
     } else {
       const int byte = j * 1024 + lane * 16;
       const int krow = byte / (2 * R), pos = (byte % (2 * R)) >> 4;
-      const int cc = pos ^ ks_swz(krow);
+      const int cc = pos ^ (ks_swz(krow) & (R / 8 - 1));
       const int col = min(row0 + cc * 8, rows - 8);
       src = base + (int64_t)(k0 + krow) * ld + col;
     }
@@ -135,7 +136,7 @@ template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename 
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   // 2 waves per SIMD = two 4-wave blocks (or one 8-wave block) per CU
   constexpr int NT = 64 * WM * WN, NWAVES = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;      // 16x16 fragments per wave
-  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0, "tile/wave shape");
+  static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/wave shape");
   static_assert(AKC || (BM & (BM - 1)) == 0, "k-strided A tiles need a power-of-two BM (XOR swizzle range)");
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE_BYTES = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // [stage][A|B]
@@ -337,6 +338,13 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
     if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 1, per_split, ws_bytes);
     return launch_cfg<256, 256, 2, 4, AKC, BKC, EPI, OutT>(a, st);
   }
+  // small problems (TextBert at 20 tokens/sample, the classifier): 128x128 tiles leave most CUs idle; 64x64 tiles (32 KB of LDS,
+  // >= 4 blocks per CU) quadruple the grid.  Used when the 128x128 grid would not even fill half of the 512 block slots.
+  if (force_tile == 64 || (force_tile == 0 && want_split == 0 && (int64_t)((a.M + 127) / 128) * tn < 256)) {
+    a.tiles_m = (a.M + 63) / 64; a.tiles_n = (a.N + 63) / 64;
+    if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 4, per_split, ws_bytes);
+    return launch_cfg<64, 64, 2, 2, AKC, BKC, EPI, OutT>(a, st);
+  }
   int bm = 128;
   if constexpr (AKC) {
     if (force_tile == 0 && want_split == 0) {
@@ -393,7 +401,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 128 || ft == 160 || ft == 192 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 128, 160, 192 or 256");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192 or 256");
   hipStream_t st = (hipStream_t)stream;
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;

@@ -121,7 +121,7 @@ def test_wgrad_split_k_and_fused_bias_grad(R, M, N, split):
         ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4)
 
 
-@pytest.mark.parametrize("tile", [128, 160, 192, 256])
+@pytest.mark.parametrize("tile", [64, 128, 160, 192, 256])
 def test_both_tile_configs_all_layouts(tile):
     ops, capi = _mods()
     M, N, K = 600, 520, 712          # ragged in every dimension for both tile sizes; K % 64 != 0
