@@ -56,44 +56,61 @@ def _fused_qkv(att):
 
 
 # ------------------------------------------------------------------------------------------------ linear
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+def _padded_views(weight, bias):
+    """GEMM-shaped views over a prepared nn.Linear's storage: rows padded to a multiple of 8 (zero rows live behind the
+    parameter in flat storage), row stride already a multiple of 8.  -> (w bf16, dW f32, b f32 | None, db f32 | None, n_pad, k_pad)"""
+    w, g = _w(weight), weight.grad
+    n, k_pad = weight.shape[0], w.stride(0)
+    n_pad = _pad8(n)
+    wv = torch.as_strided(w, (n_pad, k_pad), (k_pad, 1))
+    gv = torch.as_strided(g, (n_pad, k_pad), (k_pad, 1))
+    bv = dbv = None
+    if bias is not None:
+        bv = torch.as_strided(bias.data, (n_pad,), (1,))
+        dbv = torch.as_strided(bias.grad, (n_pad,), (1,))
+    return wv, gv, bv, dbv, n_pad, k_pad
+
+
 class LinearFn(Function):
-    """y = x W^T + b  (nn.Linear sites outside the encoder layers: input projections, classifier, pointer q/k)"""
+    """y = x W^T + b  (nn.Linear sites outside the encoder layers: input projections, classifier, pointer q/k).
+    Any in_features / out_features: both are zero-padded to multiples of 8 (in storage for the weights, on the fly for x / dy)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, out_f32):
         ctx.weight, ctx.bias = weight, bias
+        wv, _, bv, _, n_pad, k_pad = _padded_views(weight, bias)
+        n, k = weight.shape
         x2 = x.reshape(-1, x.shape[-1])
-        w = _w(weight)
-        k_pad = w.stride(0) if w.stride(0) != w.shape[1] else w.shape[1]
-        if x2.shape[1] != w.shape[1]:
-            raise capi.SamHipError("LinearFn: input width %d != in_features %d" % (x2.shape[1], w.shape[1]))
-        if k_pad != x2.shape[1] or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.dtype != BF16:
+        if x2.shape[1] != k:
+            raise capi.SamHipError("LinearFn: input width %d != in_features %d" % (x2.shape[1], k))
+        if k_pad != k or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.dtype != BF16 or x2.data_ptr() % 16:
             xp = torch.zeros((x2.shape[0], k_pad), dtype=BF16, device=x.device)   # zero-padded K (e.g. 3002 -> 3008, 4 -> 8)
-            xp[:, : x2.shape[1]] = x2
+            xp[:, :k] = x2
             x2 = xp
-        wfull = torch.as_strided(w, (w.shape[0], k_pad), (w.stride(0), 1))
-        y = ops.gemm(x2, wfull, epilogue=capi.EPI_BIAS, bias=bias, out_dtype=torch.float32 if out_f32 else BF16)
+        y = ops.gemm(x2, wv, epilogue=capi.EPI_BIAS, bias=bv, out_dtype=torch.float32 if out_f32 else BF16)
         ctx.save_for_backward(x2)
-        ctx.in_shape, ctx.in_dtype, ctx.k_pad = x.shape, x.dtype, k_pad
-        return y.view(*x.shape[:-1], weight.shape[0])
+        ctx.in_shape, ctx.in_dtype = x.shape, x.dtype
+        return y[:, :n].view(*x.shape[:-1], n) if n_pad == n else y[:, :n].reshape(*x.shape[:-1], n)
 
     @staticmethod
     def backward(ctx, dy):
         (x2,) = ctx.saved_tensors
         weight, bias = ctx.weight, ctx.bias
-        n = weight.shape[0]
+        wv, gv, _, dbv, n_pad, k_pad = _padded_views(weight, bias)
+        n, k = weight.shape
         dy2 = dy.reshape(-1, n)
-        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8:
-            dy2 = dy2.to(BF16).contiguous()
-        w = _w(weight)
-        wfull = torch.as_strided(w, (n, ctx.k_pad), (w.stride(0), 1))
-        g = weight.grad
-        gfull = torch.as_strided(g, (n, ctx.k_pad), (g.stride(0), 1))
-        ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gfull, accumulate=True, split_k=-1,
-                 bias_grad=None if bias is None else bias.grad)                              # dW += dy^T x ; db += colsum(dy)
+        if n_pad != n or dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+            dp = torch.zeros((dy2.shape[0], n_pad), dtype=BF16, device=dy.device)
+            dp[:, :n] = dy2
+            dy2 = dp
+        ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)   # dW += dy^T x ; db += colsum(dy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy2, wfull, b_kcontig=False)[:, : ctx.in_shape[-1]]               # dx = dy W
+            dx = ops.gemm(dy2, wv, b_kcontig=False)[:, :k]                                   # dx = dy W
             dx = dx.reshape(ctx.in_shape).to(ctx.in_dtype)
         return dx, None, None, None
 

@@ -62,17 +62,19 @@ class FlatParams:
         else:
             self.group_of = [0] * len(order)
         self.params = order
-        self.layout = []  # (offset, rows, cols, stride) per param
-        off = 0
+        self.layout = []  # (offset, rows, cols, stride) per param; 2-D params also get zero rows up to a multiple of 8
+        off = 0                                                        # (any out_features works as a GEMM N / K / M dimension)
         for p in order:
             if p.dim() == 2:
                 rows, cols = p.shape
                 stride = _round_up(cols, ALIGN)
+                alloc_rows = _round_up(rows, ALIGN)
             else:
                 rows, cols = 1, p.numel()
                 stride = _round_up(cols, ALIGN)
+                alloc_rows = 1
             self.layout.append((off, rows, cols, stride))
-            off += rows * stride
+            off += alloc_rows * stride
         self.numel = _round_up(off, ALIGN)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.numel, dtype=torch.float32, device=device)
@@ -89,8 +91,7 @@ class FlatParams:
             p._sam_flat = self
             p._sam_index = i
             if i + 1 == len(order) or self.group_of[i + 1] != self.group_of[i]:
-                o, r, c, s = self.layout[i]
-                self.segment_ends.append(_round_up(o + r * s, ALIGN) if i + 1 < len(order) else self.numel)
+                self.segment_ends.append(self.layout[i + 1][0] if i + 1 < len(order) else self.numel)
         self.refresh_shadows()
 
     def _view(self, buf, i, p):
@@ -118,8 +119,8 @@ class FlatParams:
         if not idx or idx != list(range(idx[0], idx[-1] + 1)):
             raise ValueError("module parameters are not contiguous in flat storage")
         o0 = self.layout[idx[0]][0]
-        o, r, c, s_ = self.layout[idx[-1]]
-        return o0, o + r * s_
+        last = idx[-1]
+        return o0, (self.layout[last + 1][0] if last + 1 < len(self.layout) else self.numel)
 
     # ---- fused views -----------------------------------------------------------------------------
     @staticmethod

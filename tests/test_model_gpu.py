@@ -110,3 +110,107 @@ def test_state_dict_keys_match_oracle_and_roundtrip():
     for k, v in ref.state_dict().items():
         assert torch.equal(sd[k].cpu(), v), k
     assert [len(gr["params"]) for gr in model.get_optimizer_parameters(1e-4)] == [len(gr["params"]) for gr in ref.get_optimizer_parameters(1e-4)]
+
+
+def _small_full_model(ctx, layers, shapes, vocab=300, seed=0):
+    """(hip model, oracle model) with identical weights; dropout off; TextBert 1 layer"""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import mmt_config_dict, text_bert_config_dict
+    T, n_obj, n_ocr, n_dec = shapes
+    md = mmt_config_dict(ctx, layers, n_dec=n_dec, T=T, n_obj=n_obj, n_ocr=n_ocr)
+    md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, obj_drop=0.0, ocr_drop=0.0)
+    td = dict(text_bert_config_dict(), num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500)
+    torch.manual_seed(seed)
+    ref = O.SAM4C(O.BertConfig.from_dict(md), O.BertConfig.from_dict(td), num_answers=vocab)
+    with torch.no_grad():           # spread the LayerNorm gains / biases so that nothing is hidden by the 1/0 init
+        for n_, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
+    model = M.SAM4C(M.BertConfig.from_dict(md), M.BertConfig.from_dict(td), num_answers=vocab, bos_idx=1)
+    model.load_state_dict(ref.state_dict())
+    return model, ref
+
+
+@pytest.mark.parametrize("ctx,layers,shapes", [(3, ("n", "s"), (20, 100, 50, 12)), (5, ("s", "n", "s"), (20, 100, 50, 12))])
+def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
+    """whole model (input encoders, TextBert, MMT, classifier, pointer net, masked BCE): loss and gradients vs the fp32 oracle"""
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import masked_bce_loss
+    model, ref = _small_full_model(ctx, layers, shapes)
+    bd_cpu = make_batch(3, *shapes, vocab=300, context=ctx, device="cpu", seed=11)
+    bd_cpu["question_indices"] = bd_cpu["question_indices"] % 500
+    ref.train()
+    out_ref = ref(clone_batch(bd_cpu))["textvqa_scores"]
+    loss_ref = O.m4c_decoding_bce_with_mask_loss(out_ref, bd_cpu["targets"], bd_cpu["train_loss_mask"])
+    loss_ref.backward()
+    model.cuda().train()
+    fp = prepare(model)
+    bd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd_cpu.items()}
+    fp.zero_grad()
+    out = model(bd)["textvqa_scores"]
+    loss = masked_bce_loss(bd)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert tuple(out.shape) == tuple(out_ref.shape)
+    e = rel_err(out, out_ref.detach())
+    assert e < 0.03, e
+    assert abs(loss.item() - loss_ref.item()) < 0.01 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    # padded OCR columns carry the literal -10000 (sa_m4c.py:893)
+    pad = (bd_cpu["pad_ocr_mask"] == 0)
+    assert (out.cpu()[:, :, 300:][pad.unsqueeze(1).expand(-1, out.shape[1], -1)] < -9000).all()
+    bad = []
+    refp = dict(ref.named_parameters())
+    biggest = max(p.grad.norm().item() for p in ref.parameters() if p.grad is not None)
+    for pn, p in model.named_parameters():
+        g_ref = refp[pn].grad
+        # d(key.bias) is mathematically 0 (softmax shift invariance): only rounding noise on both sides -> skip ~zero references
+        if g_ref is None or g_ref.norm().item() < 1e-5 * biggest:
+            assert p.grad.norm().item() < 1e-2 * biggest, pn
+            continue
+        e = ((p.grad.cpu().double() - g_ref.double()).norm() / g_ref.double().norm()).item()
+        if e > 0.05:
+            bad.append((pn, round(e, 4)))
+    assert not bad, bad
+
+
+def test_mmt_stress_shape_runs_and_matches_oracle():
+    """BASELINE config 5 shapes: 200 obj + 100 OCR + 30 dec (+20 text) = 350 tokens; 1 sample, 2 layers"""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import make_batch, mmt_config_dict
+    shapes = (20, 200, 100, 30)
+    md = mmt_config_dict(3, ("n", "s"), n_dec=30, T=20, n_obj=200, n_ocr=100)
+    md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(1)
+    ref = O.MMT(O.BertConfig.from_dict(md)).eval()
+    mmt = M.MMT(M.BertConfig.from_dict(md)).eval()
+    mmt.load_state_dict(ref.state_dict()); mmt.cuda()
+    bd = make_batch(1, *shapes, vocab=100, device="cpu", seed=5)
+    g = torch.Generator().manual_seed(2)
+    extra = dict(text_bert_emb=torch.randn(1, 20, 768, generator=g), obj_mmt_in=torch.randn(1, 200, 768, generator=g),
+                 ocr_mmt_in=torch.randn(1, 100, 768, generator=g))
+    ans = torch.randn(100, 768, generator=g)
+    bd.update(extra)
+    with torch.no_grad():
+        seq_ref = ref(dict(bd), fixed_ans_emb=ans)["mmt_seq_output"]
+        gbd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd.items()}
+        seq = mmt(gbd, fixed_ans_emb=ans.cuda())["mmt_seq_output"]
+    assert seq.shape == (1, 350, 768)
+    assert rel_err(seq, seq_ref) < 0.03
+
+
+def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    model, ref = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    losses = [tr.step(clone_batch(batch)).item() for _ in range(8)]
+    assert all(np.isfinite(losses)) and losses[-1] < 0.7 * losses[0], losses
+    assert tr.global_step == 8 and abs(tr.current_lrs()[0] - 1e-3 * (0.2 + 0.8 * 8 / 1000)) < 1e-9
+    sd = tr.state_dict()
+    assert list(sd["model_state_dict"]) == list(ref.state_dict())
+    ref.load_state_dict(sd["model_state_dict"])                   # a checkpoint written here loads into the reference layout
+    tr.load_model_state_dict({"module." + k: v for k, v in sd["model_state_dict"].items()})
