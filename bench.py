@@ -38,7 +38,9 @@ def profile_step(trainer, batch):
     """one instrumented step: HIP events around every C-ABI launch, on the stream the kernels run on"""
     from sam_textvqa_amd import _capi as capi
     from sam_textvqa_amd.synthetic import clone_batch
-    capi.profiler = []
+    torch.cuda.synchronize()
+    torch.cuda._sleep(int(40e6))     # ~20 ms of GPU spin: the host enqueues the whole step ahead of the GPU, so every
+    capi.profiler = []               # event pair brackets kernel execution only (no host-launch gaps inside the brackets)
     trainer.step(clone_batch(batch))
     torch.cuda.synchronize()
     recs, capi.profiler = capi.profiler, None
@@ -51,6 +53,30 @@ def profile_step(trainer, batch):
         a["flops"] += meta.get("flops", 0.0)
         a["bytes"] += meta.get("bytes", 0.0)
     return agg
+
+
+def pmc_traffic(kernel_key):
+    """HBM bytes per launch for `kernel_key` from the committed PMC summary (profiles/*_pmc_traffic.json, produced by
+    tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files:
+        return None
+    kern = json.load(open(files[-1]))["kernels"]
+    m = re.match(r"gemm<a_kc=(\d),b_kc=(\d),epi=(\d),f32=(\d)>", kernel_key)
+    if m:
+        tf = {"0": "false", "1": "true"}
+        pat = re.compile(r"gemm_kernel<\d+, \d+, \d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
+        sel = [v for k, v in kern.items() if pat.match(k)]
+    else:
+        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
+        sel = [v for k, v in kern.items() if any(k.startswith(n) for n in names)]
+    n = sum(v["launches_profiled"] for v in sel)
+    if not n:
+        return None
+    calls = max(v["launches_profiled"] for v in sel) if not m else n
+    return round(sum(v["hbm_bytes"] * v["launches_profiled"] for v in sel) / calls)
 
 
 def roofline_from(agg):
@@ -69,11 +95,11 @@ def roofline_from(agg):
     if top["kernel"].startswith("gemm"):
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
         roof = dict(kernel=top["kernel"], bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                    traffic=None, avg_launch_us=top["avg_us"], launches_per_step=a["calls"], flops_per_launch=a["flops"] / a["calls"])
+                    traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], flops_per_launch=a["flops"] / a["calls"])
     else:
         ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
         roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
-                    traffic=None, avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
+                    traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
     return roof, table[:12]
 
 

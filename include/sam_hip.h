@@ -80,9 +80,13 @@ typedef struct sam_gemm_desc {
                          accumulate=1, SAM_EPI_NONE.  Partials go to `ws` and are summed in a fixed order (bit-reproducible, no atomics). */
   float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] += sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad. */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
-  int32_t force_tile; /* 0: heuristic; 128 / 256: force the 128x128 (4-wave) or 256x256 (8-wave) block tile (testing, tuning) */
+  int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height (testing, tuning) */
+  int32_t defer_reduce;  /* split-K only: 1 = leave the partials in ws and let the caller run sam_gemm_splitk_reduce (separately timeable) */
+  int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
+/* C[m,n] += sum_s ws[s][m,n] ; bias_grad[m] += sum_s ws_bias[s][m]  (ws layout as written by sam_gemm_bf16; fixed order) */
+int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream);
 
 /* ---- BertLayerNorm, sam/sa_m4c.py:1016-1028 (TF style, eps inside the sqrt, biased variance) ----
  * x [M,D] bf16 or fp32 (x_is_f32) -> y bf16, plus per-row mean / rstd (fp32) for the backward. D % 4 == 0, D <= 2048. */

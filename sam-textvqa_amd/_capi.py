@@ -18,7 +18,8 @@ class GemmDesc(C.Structure):
                 ("A", _vp), ("lda", _i64), ("B", _vp), ("ldb", _i64), ("C", _vp), ("ldc", _i64),
                 ("bias", _vp), ("residual", _vp), ("ldr", _i64),
                 ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i64),
-                ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64), ("force_tile", C.c_int32)]
+                ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64), ("force_tile", C.c_int32),
+                ("defer_reduce", C.c_int32), ("split_k_used", C.c_int32)]
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)
@@ -33,6 +34,7 @@ SIGNATURES = {
     "sam_mask_bits_spatial": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp],
     "sam_abi_version": [],
     "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
+    "sam_gemm_splitk_reduce": [_vp, _i, _i, _i, _vp, _i64, _vp, _vp],
     "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],
     "sam_layernorm_bwd": [_vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _f, _u64, _u64, _vp, _vp, _vp, _i, _vp, _vp],
     "sam_layernorm_bwd_ws_bytes": [_i],

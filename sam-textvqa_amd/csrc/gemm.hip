@@ -32,6 +32,8 @@ struct GemmArgs {
   int split_k;        // >1: grid = tiles * split_k; split s stores its fp32 partial tile into ws[s] (wgrad: few tiles, very long K)
   float* ws;          // [split_k][M*N] partial outputs, then [split_k][M] partial bias gradients; reduced by splitk_reduce_kernel
   float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
+  int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
+  int* split_used;    // host pointer: receives the split factor actually launched
 };
 
 // ---- LDS images (one 64-deep k-tile) -----------------------------------------------------------------
@@ -302,7 +304,8 @@ int launch_cfg(GemmArgs a, hipStream_t st) {
     once = true;
   }
   gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(64 * WM * WN), LDS, st>>>(a);
-  if (a.split_k > 1) {
+  if (a.split_used) *a.split_used = a.split_k;
+  if (a.split_k > 1 && !a.defer_reduce) {
     const int64_t mn4 = (int64_t)a.M * a.N / 4;
     splitk_reduce_kernel<<<dim3((unsigned)min((int64_t)2048, (mn4 + 255) / 256)), dim3(256), 0, st>>>(a.ws, a.split_k, a.M, a.N, (float*)a.C, a.ldc, a.bias_grad);
   }
@@ -367,6 +370,14 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
 
 }  // namespace
 
+extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream) {
+  SAM_REQUIRE(ws && C && split_k >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0, "sam_gemm_splitk_reduce: bad arguments");
+  const int64_t mn4 = (int64_t)M * N / 4;
+  splitk_reduce_kernel<<<dim3((unsigned)min((int64_t)2048, (mn4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(ws, split_k, M, N, C, ldc, bias_grad);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   SAM_REQUIRE(d, "sam_gemm_bf16: null descriptor");
   SAM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sam_gemm_bf16: empty problem %dx%dx%d", d->M, d->N, d->K);
@@ -390,6 +401,8 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.split_k = 1;
   a.bias_grad = d->bias_grad;
   a.ws = d->ws;
+  a.defer_reduce = d->defer_reduce;
+  a.split_used = const_cast<int32_t*>(&d->split_k_used);
   SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
   int want_split = (d->split_k == 1) ? 0 : d->split_k;
   if (want_split != 0) {

@@ -135,9 +135,12 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     if split_k not in (0, 1):
         want = split_k if split_k > 0 else 32
         ws = _workspace(min(want * (M * N + M) * 4, 96 << 20), a.device, "splitk")
-        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel() * 4
+        d.ws, d.ws_bytes, d.defer_reduce = ws.data_ptr(), ws.numel() * 4, 1
     capi.call("sam_gemm_bf16", d, capi.stream_handle(),
               meta=dict(kernel="gemm<a_kc=%d,b_kc=%d,epi=%d,f32=%d>" % (d.a_kcontig, d.b_kcontig, d.epilogue, d.c_is_f32), flops=2.0 * M * N * K, shape=(M, N, K)))
+    if d.split_k_used > 1:   # the fixed-order reduction of the split-K partials is its own launch (and its own profile row)
+        capi.call("sam_gemm_splitk_reduce", d.ws, d.split_k_used, M, N, out.data_ptr(), out.stride(0), d.bias_grad, capi.stream_handle(),
+                  meta=dict(kernel="splitk_reduce", bytes=4.0 * M * N * (d.split_k_used + 2)))
     return out
 
 
