@@ -119,6 +119,11 @@ int sam_ptr_scores_fwd(const void* q, const void* k, const uint8_t* ocr_mask, in
 int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const void* q, const void* k, int B, int S, int No, int D, float scale,
                        void* dq, void* dk, void* stream);
 
+/* ---- word-embedding backward (BertEmbeddings.word_embeddings of TextBert, sam/sa_m4c.py:377,383): grad[idx[t],:] += dy[t,:] ----
+ * dy bf16 [T,D]; idx int64 [T]; grad fp32 [rows, ldg]; rows outside [0,rows) and row == padding_idx (nn.Embedding semantics; -1 = none)
+ * are skipped.  fp32 atomics (rows may repeat). */
+int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream);
+
 /* ---- optimizer step over ONE flat fp32 parameter buffer: clip_grad_norm_ + Adam, train.py:139-142, task_utils.py:33-57 ----
  * sam_sumsq_f32: out[0] = sum g^2 (deterministic two-stage; every data-parallel rank gets the identical value).
  * sam_adam_step: torch.optim.Adam semantics (bias-corrected, eps outside the sqrt); per-segment learning rates

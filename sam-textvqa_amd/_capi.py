@@ -43,6 +43,7 @@ SIGNATURES = {
     "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _i64, _vp],
     "sam_ptr_scores_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i64, _i64, _vp],
     "sam_ptr_scores_bwd": [_vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
+    "sam_embedding_bwd": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
     "sam_sumsq_ws_bytes": [],
     "sam_sumsq_f32": [_vp, _i64, _vp, _vp, _vp],
     "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],

@@ -145,6 +145,30 @@ def layer_norm(x, ln):
     return LayerNormFn.apply(x, ln.weight, ln.bias, ln.variance_epsilon)
 
 
+class EmbeddingFn(Function):
+    """table[idx] with the gradient scattered straight into the flat gradient buffer (word embeddings: 30522 x 768 table,
+    B*20 mostly-distinct rows per step; torch's dense embedding backward costs ~70 us per table)"""
+
+    @staticmethod
+    def forward(ctx, idx, weight, padding_idx):
+        ctx.weight, ctx.padding_idx = weight, padding_idx
+        ctx.save_for_backward(idx)
+        return torch.nn.functional.embedding(idx, _w(weight))          # bf16 rows
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16 or not dy2.is_contiguous():
+            dy2 = dy2.to(BF16).contiguous()
+        ops.embedding_bwd(dy2, idx.reshape(-1).contiguous(), ctx.weight.grad, ctx.padding_idx)
+        return None, None, None
+
+
+def embedding(idx, emb):
+    return EmbeddingFn.apply(idx, emb.weight, -1 if emb.padding_idx is None else emb.padding_idx)
+
+
 # ------------------------------------------------------------------------------------------------ encoder layer
 class EncoderLayerFn(Function):
     """One BERT-style encoder layer (spatial or plain — the difference is entirely in `allow`), forward and backward,

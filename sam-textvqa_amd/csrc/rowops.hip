@@ -347,6 +347,20 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* 
   }
 }
 
+// embedding backward: grad_table[idx[t], :] += dy[t, :]   (fp32 hardware atomics: rows may repeat)
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg) {
+  const int t = blockIdx.x;
+  const int64_t row = idx[t];
+  if (row < 0 || row >= rows || row == padding_idx) return;   // nn.Embedding(padding_idx=...) never accumulates into that row
+  for (int c = threadIdx.x; c * 4 < D; c += 256) {
+    float v[4];
+    Ld4<bf16_t>::ld(dy, (int64_t)t * ldd + 4 * c, v);
+    float* g = grad + row * ldg + 4 * c;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(g + e, v[e]);
+  }
+}
+
 template <typename InT>
 int ln_fwd_dispatch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D,
                     void* y, int64_t ldy, float* mean, float* rstd) {
@@ -449,6 +463,14 @@ extern "C" int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld
   SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0 && S <= 256 && No <= 256, "sam_ptr_scores_bwd: bad shape (S, No <= 256)");
   ptr_bwd_kernel<<<dim3(B, S + No), dim3(256), 0, (hipStream_t)stream>>>(dscores, ld_b, ld_s, (const bf16_t*)q, (const bf16_t*)k, S, No, D,
                                                                                           scale, (bf16_t*)dq, (bf16_t*)dk);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream) {
+  SAM_REQUIRE(dy && idx && grad, "sam_embedding_bwd: null pointer");
+  SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && rows > 0, "sam_embedding_bwd: bad shape");
+  embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

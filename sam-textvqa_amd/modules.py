@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from . import ops
-from .autograd import (BF16, AttentionFn, PtrScoresFn, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, PtrScoresFn, embedding, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -306,8 +306,10 @@ class BertEmbeddings(_HipModule):
     def forward(self, input_ids):
         self._ready()
         n = input_ids.size(1)
-        pos = torch.arange(n, dtype=torch.long, device=input_ids.device).unsqueeze(0).expand_as(input_ids)
-        e = self.word_embeddings(input_ids) + self.position_embeddings(pos) + self.token_type_embeddings(torch.zeros_like(input_ids))
+        # positions are 0..n-1 and the token type is 0 for every token: plain slices (their backward is a batch reduction, not a
+        # scatter); the word rows are gathered from the bf16 shadow table and their gradient is scattered by sam_embedding_bwd
+        e = (embedding(input_ids, self.word_embeddings).float() + self.position_embeddings.weight[:n]
+             + self.token_type_embeddings.weight[0])
         return F.dropout(layer_norm(e, self.LayerNorm), self.dropout_p, self.training)
 
 
@@ -408,8 +410,8 @@ class PrevPredEmbeddings(_HipModule):
         ocr_idx = (prev_inds - n_ans).clamp(min=0) + (torch.arange(b, device=prev_inds.device) * n_ocr).unsqueeze(-1)
         from_ocr = F.embedding(ocr_idx, ocr)
         raw = torch.where(is_ocr.unsqueeze(-1), from_ocr, from_ans)
-        pos = torch.arange(s, dtype=torch.long, device=prev_inds.device).unsqueeze(0).expand(b, s)
-        emb = self.position_embeddings(pos) + self.token_type_embeddings(is_ocr.long())
+        tt = self.token_type_embeddings.weight
+        emb = self.position_embeddings.weight[:s] + torch.where(is_ocr.unsqueeze(-1), tt[1], tt[0])      # [B, S, D]
         emb = F.dropout(layer_norm(emb, self.emb_layer_norm), self.dropout_p, self.training)
         return raw + emb
 

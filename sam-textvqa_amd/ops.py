@@ -243,3 +243,10 @@ def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm
 def cast_bf16(x, y):
     capi.call("sam_cast_f32_to_bf16", capi.ptr(x), capi.ptr(y), x.numel(), capi.stream_handle())
     return y
+
+
+def embedding_bwd(dy, idx, grad_table, padding_idx=-1):
+    """grad_table[idx[t], :] += dy[t, :]  (dy bf16 [T,D], idx int64 [T], grad_table fp32 [rows, D]); padding_idx rows are skipped"""
+    t, d = dy.shape
+    capi.call("sam_embedding_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(idx), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table), grad_table.stride(0),
+              capi.stream_handle())

@@ -139,7 +139,7 @@ def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
     from sam_textvqa_amd.trainer import masked_bce_loss
     model, ref = _small_full_model(ctx, layers, shapes)
     bd_cpu = make_batch(3, *shapes, vocab=300, context=ctx, device="cpu", seed=11)
-    bd_cpu["question_indices"] = bd_cpu["question_indices"] % 500
+    bd_cpu["question_indices"] = (bd_cpu["question_indices"] % 499 + 1) * bd_cpu["question_mask"]      # padded tokens -> id 0 = padding_idx
     ref.train()
     out_ref = ref(clone_batch(bd_cpu))["textvqa_scores"]
     loss_ref = O.m4c_decoding_bce_with_mask_loss(out_ref, bd_cpu["targets"], bd_cpu["train_loss_mask"])
