@@ -39,6 +39,15 @@ int sam_mask_bits_from_additive(const float* mask, int B, int N, int NW, uint32_
 int sam_mask_bits_spatial(const uint32_t* base, const int8_t* adj, int B, int N, int NW, int T, int n_oo, int R, int H,
                           unsigned quadrant_bits, uint32_t* out, void* stream);
 
+/* relation-type tensor already expanded per head over the WHOLE sequence, int8 [B,H,N,N] (non-zero = visible; the layout
+ * BASELINE.json's north_star names): out = bits(rel) & base (base may be NULL).  Equivalent input to sam_mask_bits_spatial. */
+int sam_mask_bits_from_int8_bhnn(const int8_t* rel, const uint32_t* base, int B, int H, int N, int NW, uint32_t* out, void* stream);
+
+/* ---- spatial relation graph, sam/spatial_utils.py:92-218 + :33-52 + sam/datasets/textvqa_dataset.py:378-409 ----
+ * boxes f64 [B,N,4] normalised xyxy (all-zero row = padding) -> multi-hot int8 [B,N,N,12] for spatial context c in {1,3,5,7,9};
+ * one thread per ordered pair, float64 in the reference's operation order. */
+int sam_spatial_relation_tensor(const double* boxes, int B, int N, int context, double distance_threshold, int8_t* out, void* stream);
+
 /* ---- fused attention, sam/sa_m4c.py:563-598 (+ the plain BertSelfAttention of 'n' layers / TextBert) ----
  * qkv bf16 [B*N, 3*H*64] (q|k|v, straight out of the fused QKV projection); allow as above with element strides
  * (allow_stride_h = 0 broadcasts one mask over heads); out bf16 [B*N, H*64]; lse2 f32 [B,H,N] = log2-domain

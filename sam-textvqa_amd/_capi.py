@@ -33,6 +33,8 @@ SIGNATURES = {
     "sam_mask_bits_from_additive": [_vp, _i, _i, _i, _vp, _vp],
     "sam_mask_bits_spatial": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp],
     "sam_abi_version": [],
+    "sam_mask_bits_from_int8_bhnn": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "sam_spatial_relation_tensor": [_vp, _i, _i, _i, C.c_double, _vp, _vp],
     "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
     "sam_gemm_splitk_reduce": [_vp, _i, _i, _i, _vp, _i64, _vp, _vp],
     "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],

@@ -41,6 +41,22 @@ __global__ void from_additive_kernel(const float* mask, int B, int N, int NW, ui
   out[idx] = bits;
 }
 
+// relation tensor already in per-head layout int8 [B,H,N,N] (the format BASELINE.json's north_star names): bit = rel != 0 (& base)
+__global__ void from_int8_bhnn_kernel(const int8_t* rel, const uint32_t* base, int B, int H, int N, int NW, uint32_t* out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)B * H * N * NW) return;
+  const int w = idx % NW;
+  const int64_t row = idx / NW;                 // (b*H + h)*N + q
+  const int q = row % N;
+  const int64_t b = row / ((int64_t)H * N);
+  const int8_t* p = rel + row * N + 32 * w;
+  uint32_t bits = 0;
+  for (int k = 0; k < 32; ++k)
+    if (32 * w + k < N && p[k] != 0) bits |= 1u << k;
+  if (base) bits &= base[(b * N + q) * NW + w];
+  out[idx] = bits;
+}
+
 // quadrant ids follow the reference's 3x3 numbering over (text, obj+ocr, dec) x (text, obj+ocr, dec)
 __device__ __forceinline__ int region_of(int x, int T, int n_oo) { return x < T ? 0 : (x < T + n_oo ? 1 : 2); }
 
@@ -94,6 +110,15 @@ extern "C" int sam_mask_bits_from_additive(const float* mask, int B, int N, int 
   SAM_REQUIRE(B > 0 && N > 0 && NW * 32 >= N, "sam_mask_bits_from_additive: bad shape");
   const int64_t total = (int64_t)B * N * NW;
   from_additive_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(mask, B, N, NW, out);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_mask_bits_from_int8_bhnn(const int8_t* rel, const uint32_t* base, int B, int H, int N, int NW, uint32_t* out, void* stream) {
+  SAM_REQUIRE(rel && out, "sam_mask_bits_from_int8_bhnn: null pointer");
+  SAM_REQUIRE(B > 0 && H > 0 && N > 0 && NW * 32 >= N, "sam_mask_bits_from_int8_bhnn: bad shape");
+  const int64_t total = (int64_t)B * H * N * NW;
+  from_int8_bhnn_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(rel, base, B, H, N, NW, out);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -250,3 +250,22 @@ def embedding_bwd(dy, idx, grad_table, padding_idx=-1):
     t, d = dy.shape
     capi.call("sam_embedding_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(idx), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table), grad_table.stride(0),
               capi.stream_handle())
+
+
+def mask_bits_from_int8_bhnn(rel, base_bits=None):
+    """rel int8 [B,H,N,N] (non-zero = visible), optional base bits [B,1,N,NW] -> uint32 [B,H,N,NW]"""
+    _chk(rel, torch.int8, "rel")
+    b, h, n, n2 = rel.shape
+    nw = words_per_row(n)
+    out = torch.empty((b, h, n, nw), dtype=torch.int32, device=rel.device)
+    capi.call("sam_mask_bits_from_int8_bhnn", capi.ptr(rel), capi.ptr(base_bits), b, h, n, nw, capi.ptr(out), capi.stream_handle())
+    return out
+
+
+def spatial_relation_tensor(boxes, context=3, distance_threshold=0.5):
+    """boxes f64 [B,N,4] on the GPU -> int8 [B,N,N,12] (HIP kernel; same semantics as spatial_graph.relation_tensor)"""
+    _chk(boxes, torch.float64, "boxes")
+    b, n, _ = boxes.shape
+    out = torch.empty((b, n, n, 12), dtype=torch.int8, device=boxes.device)
+    capi.call("sam_spatial_relation_tensor", capi.ptr(boxes), b, n, int(context), float(distance_threshold), capi.ptr(out), capi.stream_handle())
+    return out

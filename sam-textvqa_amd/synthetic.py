@@ -44,7 +44,11 @@ def make_batch(batch_size, T=20, n_obj=100, n_ocr=50, n_dec=12, vocab=5000, cont
 
     obj_b, ocr_b = boxes(n_obj, 0.21, obj_mask), boxes(n_ocr, 0.08, ocr_mask)
     all_b = torch.cat([obj_b, ocr_b], dim=1).to(device)
-    adj = relation_tensor(all_b, context)                                        # int8 [B, n_oo, n_oo, 12] built on the device
+    if all_b.is_cuda:                                                            # int8 [B, n_oo, n_oo, 12] built on the device
+        from . import ops
+        adj = ops.spatial_relation_tensor(all_b.contiguous(), context)            # HIP kernel, one thread per box pair
+    else:
+        adj = relation_tensor(all_b, context)                                     # same semantics, vectorised torch (CPU baseline)
     area = lambda b: ((b[..., 2] - b[..., 0]) * (b[..., 3] - b[..., 1])).unsqueeze(-1)
     steps = torch.randint(1, n_dec + 1, (B,), generator=g)
     loss_mask = (ar(n_dec) < steps.unsqueeze(1)).float()

@@ -74,6 +74,54 @@ def test_mask_bits_bit_exact(shape, quadrants):
     assert torch.equal(ops.mask_bits_from_additive(ext.to(dev)).cpu(), base.cpu())
 
 
+def test_mask_bits_from_int8_bhnn_format():
+    """the [B,H,N,N] int8 relation-type layout named by the north star gives the same bits as the dataset layout"""
+    ops = _ops()
+    pr = make_problem(2, 20, 100, 50, 12, seed=4)
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).cuda(), pr["n_dec"])
+    want = ops.mask_bits_spatial(base, pr["adj"].cuda(), pr["T"], pr["H"], (1, 2))
+    allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], (1, 2), pr["H"])     # bool [B,H,N,N]
+    got = ops.mask_bits_from_int8_bhnn(allow.to(torch.int8).cuda())
+    assert torch.equal(got.cpu(), want.cpu())
+    sp_only = O.allow_mask(torch.ones_like(pr["key_valid"]), pr["T"], pr["n_oo"], 0, pr["adj"], (1, 2), pr["H"])
+    pad = torch.zeros(2, pr["H"], pr["N"], pr["N"], dtype=torch.int8)
+    pad[:, :, : pr["T"] + pr["n_oo"], : pr["T"] + pr["n_oo"]] = sp_only.to(torch.int8)
+    pad[:, :, pr["T"] + pr["n_oo"]:, :] = 1
+    got2 = ops.mask_bits_from_int8_bhnn(pad.cuda(), base)
+    assert torch.equal(got2.cpu(), want.cpu())
+
+
+def test_spatial_graph_kernel_matches_reference_goldens():
+    from tests import oracle_cases as OC
+    ops = _ops()
+    g = OC.load("spatial_graph")
+    for nm in ("known6", "grid", "rnd60", "cross"):
+        bx = g[nm + ".boxes"]
+        boxes = torch.from_numpy(bx)[None].cuda()
+        # Pairs whose centre direction lies EXACTLY on a sector boundary (dx = 0, dy = 0 or |dx| = |dy|; only the synthetic
+        # `grid` case has them) are classified by the last ulp of libm's asin/acos in the reference itself; there either adjacent
+        # sector is accepted.  Everywhere else the kernel must be bit-identical to the reference goldens.
+        cx, cy = 0.5 * (bx[:, 0] + bx[:, 2]), 0.5 * (bx[:, 1] + bx[:, 3])
+        dx, dy = np.abs(cx[:, None] - cx[None, :]), np.abs(cy[:, None] - cy[None, :])
+        on_boundary = (dx < 1e-12) | (dy < 1e-12) | (np.abs(dx - dy) < 1e-12)
+        for ctx in (1, 3, 5, 7, 9):
+            got = ops.spatial_relation_tensor(boxes, ctx)[0].cpu().numpy()
+            want = g["%s.ctx%d" % (nm, ctx)]
+            diff = (got != want).any(-1)
+            assert not (diff & ~on_boundary).any(), "%s ctx%d: mismatch off the sector boundaries" % (nm, ctx)
+            if nm != "grid":
+                np.testing.assert_array_equal(got, want, err_msg="%s ctx%d" % (nm, ctx))
+            else:       # boundary pairs: same number of channels set, and they overlap the reference's (adjacent sector)
+                assert (got.sum(-1) == want.sum(-1)).all()
+                assert ((got & want).sum(-1)[diff] >= (ctx - 1)).all() if ctx > 1 else True
+    # batched, at the c3 size, against the torch-vectorised builder
+    from sam_textvqa_amd.spatial_graph import relation_tensor
+    from sam_textvqa_amd.synthetic import make_batch
+    bd = make_batch(4, device="cuda", seed=9)
+    boxes = torch.cat([bd["pad_obj_bboxes"][..., :4], bd["pad_ocr_bboxes"][..., :4]], 1).double()
+    assert torch.equal(ops.spatial_relation_tensor(boxes, 5), relation_tensor(boxes, 5))
+
+
 def test_mask_bits_rejects_bad_quadrant():
     ops = _ops()
     pr = make_problem(1, 4, 10, 6, 3)
