@@ -158,26 +158,25 @@ def main():
     for _ in range(args.warmup):
         loss = trainer.step(clone_batch(batch))
     torch.cuda.synchronize()
-    if world > 1:
+    if parallel.dist.is_initialized():
         parallel.dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = trainer.step(clone_batch(batch))
     torch.cuda.synchronize()
-    if world > 1:
+    if parallel.dist.is_initialized():
         parallel.dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if parallel.dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         parallel.dist.all_reduce(t, op=parallel.dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
     if rank != 0:
-        if world > 1:
-            parallel.dist.barrier()
-            parallel.dist.destroy_process_group()
+        parallel.dist.barrier()
+        parallel.dist.destroy_process_group()
         return
     gb = args.batch * world
     res = {
@@ -199,7 +198,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.context, layers, args.vocab)
     print(json.dumps(res), flush=True)
-    if world > 1:
+    if parallel.dist.is_initialized():
         parallel.dist.barrier()
         parallel.dist.destroy_process_group()
 

@@ -19,6 +19,8 @@ class GradReducer:
         self.grad = flat_grad
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
+        # SAM_FORCE_DIST=1: run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
+        self.force = dist.is_initialized() and __import__("os").environ.get("SAM_FORCE_DIST") == "1"
         n = flat_grad.numel()
         per = max(1, bucket_bytes // flat_grad.element_size())
         # bucket k covers [n - (k+1)*per, n - k*per): ascending k = descending addresses = backward order
@@ -28,7 +30,7 @@ class GradReducer:
             lo = max(0, hi - per)
             self.buckets.append((lo, hi))
             hi = lo
-        self.overlap = overlap and flat_grad.is_cuda and self.world_size > 1
+        self.overlap = overlap and flat_grad.is_cuda and (self.world_size > 1 or self.force)
         self.stream = torch.cuda.Stream() if self.overlap else None
         self.regions = []
         self.begin_step()
@@ -61,7 +63,7 @@ class GradReducer:
     def _launch(self, k):
         lo, hi = self.buckets[k]
         chunk = self.grad[lo:hi]
-        if self.world_size == 1:
+        if self.world_size == 1 and not self.force:
             return
         if self.overlap:
             self.stream.wait_stream(torch.cuda.current_stream())
@@ -96,11 +98,14 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("SAM_FORCE_DIST") == "1") and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
         backend = "nccl" if torch.cuda.is_available() else "gloo"
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)
     return rank, local, world

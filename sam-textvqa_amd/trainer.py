@@ -38,7 +38,7 @@ class Trainer:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.max_grad_norm, self.betas, self.eps = max_grad_norm, betas, eps
         self.schedule = schedule or {}
-        if reducer is None and parallel.dist.is_initialized() and parallel.dist.get_world_size() > 1:
+        if reducer is None and parallel.dist.is_initialized() and (parallel.dist.get_world_size() > 1 or __import__("os").environ.get("SAM_FORCE_DIST") == "1"):
             reducer = parallel.GradReducer(self.flat.grad)
         self.reducer = reducer
         if reducer is not None:
