@@ -13,6 +13,9 @@
 #include "common.h"
 #include "sam_hip.h"
 #include <stdlib.h>
+#ifndef SAM_GEMM_SC1_STORES
+#define SAM_GEMM_SC1_STORES 0   // measured: no gain (within noise) on any shape of the step; kept as a build-time switch
+#endif
 
 namespace {
 
@@ -119,7 +122,14 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, 
 template <typename OutT> struct Store4;
 template <> struct Store4<bf16_t> {
   static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int) {
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + idx) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    const uint2 val = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#if SAM_GEMM_SC1_STORES
+    // write-through store: the output tile is never re-read by this kernel, keep it from evicting operand panels in the XCD's L2
+    const bf16_t* addr = reinterpret_cast<bf16_t*>(C) + idx;
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(addr), "v"(val) : "memory");
+#else
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + idx) = val;
+#endif
   }
 };
 template <> struct Store4<float> {
