@@ -82,7 +82,7 @@ struct AttnArgs {
 // forward
 // --------------------------------------------------------------------------------------------
 template <int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPAD = NKT * 16;
   unsigned char* Ks = smem;
@@ -140,43 +140,45 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnArgs a) {
         sum += p;
       }
     sum = xgroup_sum(sum);
-    // attention-prob dropout (sa_m4c.py:588): applied after the row zeroing, before PV
-    if (a.thr16 != 0) {
+    // PV, one 32-key slab (two score tiles) at a time so that only the fp32 probabilities stay live: dropout
+    // (sa_m4c.py:588: after the row zeroing, before PV), hi/lo bf16 split, then 2 x 4 MFMAs into the 4 d-tile accumulators
+    const float inv = alive ? a.inv_keep / sum : 0.f;
+    f32x4 o[4];
 #pragma unroll
-      for (int w = 0; w < NKT / 2; ++w) {
-        const u32x4 rn = philox4x32_10((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) {
+      float v8[8] = {s[2 * w][0], s[2 * w][1], s[2 * w][2], s[2 * w][3], s[2 * w + 1][0], s[2 * w + 1][1], s[2 * w + 1][2], s[2 * w + 1][3]};
+      if (a.thr16 != 0) {
+        const u32x4 rn = dropout_bits128((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
         const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
         unsigned bits = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const unsigned r16 = (rr[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
           const bool kept = r16 >= a.thr16;
-          if (!kept) s[2 * w + (e >> 2)][e & 3] = 0.f;
+          if (!kept) v8[e] = 0.f;
           bits |= (kept ? 1u : 0u) << ((e >> 2) * 16 + 4 * g + (e & 3));
         }
         bits = xgroup_or(bits);
         if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
       }
+      bf16x8 pa, pl;
+      split_pack8(v8, pa, pl);
+      bf16x8 vt[4];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) vt[dt] = lds_col_frag(Vs, w, dt, i, g);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pa, o[dt], 0, 0, 0);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pl, o[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting all V fragments costs 96 VGPRs and a wave of occupancy
     }
-    bf16x8 pa[NKT / 2], pl[NKT / 2];
+    if (q < N) {
 #pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) {
-      const float v8[8] = {s[2 * w][0], s[2 * w][1], s[2 * w][2], s[2 * w][3], s[2 * w + 1][0], s[2 * w + 1][1], s[2 * w + 1][2], s[2 * w + 1][3]};
-      split_pack8(v8, pa[w], pl[w]);
-    }
-    const float inv = alive ? a.inv_keep / sum : 0.f;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int w = 0; w < NKT / 2; ++w) {
-        const bf16x8 vt = lds_col_frag(Vs, w, dt, i, g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pa[w], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt, pl[w], acc, 0, 0, 0);
-      }
-      if (q < N) {
-        uint2 o = make_uint2(pack_bf16x2(acc[0] * inv, acc[1] * inv), pack_bf16x2(acc[2] * inv, acc[3] * inv));
-        *reinterpret_cast<uint2*>(a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 16 * dt + 4 * g) = o;
+      for (int dt = 0; dt < 4; ++dt) {
+        uint2 ov = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+        *reinterpret_cast<uint2*>(a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 16 * dt + 4 * g) = ov;
       }
     }
     if (q < N && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx + __builtin_amdgcn_logf(sum) : INFINITY;
@@ -286,7 +288,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   float* lse_s = reinterpret_cast<float*>(dOs + NPAD * ROW_BYTES);
   float* del_s = lse_s + NPAD;
   uint32_t* allowT = reinterpret_cast<uint32_t*>(del_s + NPAD);  // [NW][NPAD]
-  uint32_t* keepT = allowT + NW * NPAD;                           // [NW][NPAD]
+  uint32_t* keepT = allowT + NW * NPAD;                           // [NW][NPAD]  (reading the keep bits from global instead, to fit a
+                                                                  // third block per CU, measured slower: 100 -> 110 us)
   const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int N = a.N, Dm = a.H * HD;
   const int64_t ld = 3 * (int64_t)Dm;

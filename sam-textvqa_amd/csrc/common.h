@@ -89,7 +89,19 @@ __device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigne
   }
   return {c0, c1, c2, c3};
 }
-// dropout threshold on 16-bit lanes of the Philox output: element kept iff rnd16 >= thr16
+// Attention-probability dropout draws 8 x 16 random bits per (row, 32-key slab, lane group): Philox there costs as much VALU
+// as the whole softmax (measured +15 us on a 40 us kernel).  A counter-based integer hash (two multiplies + three xorshifts per
+// 32 bits, "lowbias32" finaliser) of the same (counter, key) tuple gives statistically clean keep masks at a third of the cost;
+// the hidden-state dropout in the GEMM epilogue / LayerNorm backward keeps Philox (one call per 8 elements, negligible there).
+__device__ __forceinline__ unsigned mix32(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ u32x4 dropout_bits128(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+  const unsigned base = mix32(c0 * 0x9E3779B1u + (c2 ^ k0)) ^ (c1 * 0x85EBCA77u + c3 * 0xC2B2AE3Du + k1);
+  return {mix32(base), mix32(base + 0x68E31DA4u), mix32(base + 0xB5297A4Du), mix32(base + 0x1B56C4E9u)};
+}
+// dropout threshold on 16-bit lanes of the random words: element kept iff rnd16 >= thr16
 __host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {
   float t = p * 65536.0f + 0.5f;
   return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (unsigned)t);
