@@ -107,7 +107,28 @@ __host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {
   return t <= 0.f ? 0u : (t >= 65535.f ? 65535u : (unsigned)t);
 }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-GELU (sam/sa_m4c.py:985-991) and its derivative.  libm's erff costs ~40 VALU with branches and made the GELU epilogues
+// 30% of their GEMMs; Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below bf16 resolution) needs one rcp, one exp2 and
+// a 5-term Horner polynomial, and the SAME exponential exp(-x^2/2) serves the Gaussian term of the derivative.
+__device__ __forceinline__ float gelu_phi_and_cdf(float x, float& cdf) {   // returns exp(-x^2/2); cdf = 0.5*(1+erf(x/sqrt2))
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  const float e = __builtin_amdgcn_exp2f(-0.72134752044448170f * x * x);        // exp(-x^2/2) = 2^(-x^2 * log2(e)/2)
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float erf_abs = 1.0f - poly * t * e;                                     // erf(|x|/sqrt2)
+  cdf = 0.5f + 0.5f * copysignf(erf_abs, x);
+  return e;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+  float cdf;
+  gelu_phi_and_cdf(x, cdf);
+  return x * cdf;
+}
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+  float cdf;
+  const float e = gelu_phi_and_cdf(x, cdf);
+  return cdf + x * 0.39894228040143268f * e;
 }
