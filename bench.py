@@ -70,7 +70,8 @@ def pmc_traffic(kernel_key):
         pat = re.compile(r"gemm_kernel<\d+, \d+, \d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
         sel = [v for k, v in kern.items() if pat.match(k)]
     else:
-        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
+        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"],
+                 "gemm_grouped_wgrad": ["gemm_group_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
         sel = [v for k, v in kern.items() if any(k.startswith(n) for n in names)]
     n = sum(v["launches_profiled"] for v in sel)
     if not n:

@@ -94,6 +94,10 @@ typedef struct sam_gemm_desc {
   int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
+/* up to 8 independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C, SAM_EPI_NONE, no split) in ONE grid: the four
+ * weight gradients of an encoder layer (dWqkv, dWo, dW1, dW2: 432 tiles of 128x128) fill the 512 resident block slots in a single
+ * round, which makes split-K and its reduction pass unnecessary.  bias_grad is honoured per problem. */
+int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);
 /* C[m,n] += sum_s ws[s][m,n] ; bias_grad[m] += sum_s ws_bias[s][m]  (ws layout as written by sam_gemm_bf16; fixed order) */
 int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream);
 

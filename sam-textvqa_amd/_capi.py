@@ -37,6 +37,7 @@ SIGNATURES = {
     "sam_spatial_relation_tensor": [_vp, _i, _i, _i, C.c_double, _vp, _vp],
     "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
     "sam_gemm_splitk_reduce": [_vp, _i, _i, _i, _vp, _i64, _vp, _vp],
+    "sam_gemm_bf16_grouped": [C.POINTER(GemmDesc), _i, _vp],
     "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],
     "sam_layernorm_bwd": [_vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _f, _u64, _u64, _vp, _vp, _vp, _i, _vp, _vp],
     "sam_layernorm_bwd_ws_bytes": [_i],

@@ -207,20 +207,20 @@ class EncoderLayerFn(Function):
         # ---- output block: y = LN(dropout(h W2^T + b2) + a)
         dz2, dy2 = ops.layernorm_bwd(dy, z2, mean2, rstd2, out.LayerNorm.weight, out.LayerNorm.weight.grad, out.LayerNorm.bias.grad,
                                      dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1])
-        ops.gemm(dy2, h, a_kcontig=False, b_kcontig=False, out=out.dense.weight.grad, accumulate=True, split_k=-1)
+        wgrads = [(dy2, h, out.dense.weight.grad, None)]          # the four weight gradients go out as ONE grouped launch at the end
         dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre)
         # ---- intermediate: h = gelu(a W1^T + b1)
-        ops.gemm(dpre, a, a_kcontig=False, b_kcontig=False, out=inter.dense.weight.grad, accumulate=True, split_k=-1,
-                 bias_grad=inter.dense.bias.grad)                                           # bias gradient fused into the wgrad
+        wgrads.append((dpre, a, inter.dense.weight.grad, inter.dense.bias.grad))          # bias gradient fused into the wgrad
         da = ops.gemm(dpre, _w(inter.dense.weight), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz2)   # + residual path
         # ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
         dz1, dy1 = ops.layernorm_bwd(da, z1, mean1, rstd1, so.LayerNorm.weight, so.LayerNorm.weight.grad, so.LayerNorm.bias.grad,
                                      dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1])
-        ops.gemm(dy1, ctxv, a_kcontig=False, b_kcontig=False, out=so.dense.weight.grad, accumulate=True, split_k=-1)
+        wgrads.append((dy1, ctxv, so.dense.weight.grad, None))
         dctx = ops.gemm(dy1, _w(so.dense.weight), b_kcontig=False)
         # ---- attention core + fused QKV projection
         dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn)
-        ops.gemm(dqkv, x, a_kcontig=False, b_kcontig=False, out=dwqkv, accumulate=True, split_k=-1, bias_grad=dbqkv)
+        wgrads.append((dqkv, x, dwqkv, dbqkv))
+        ops.wgrad_grouped(wgrads)
         dx = ops.gemm(dqkv, wqkv, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz1) if ctx.needs_input_grad[0] else None
         rid = getattr(layer, "_sam_region_id", None)
         if rid is not None and parallel.active_reducer is not None:

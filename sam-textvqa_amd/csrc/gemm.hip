@@ -146,7 +146,7 @@ template <> struct Store4<float> {
 //   <128,128,2,2>: 256 threads, 64 KB LDS, 2 blocks/CU  -- 64 flop per byte staged
 //   <256,256,2,4>: 512 threads, 128 KB LDS, 1 block/CU  -- 128 flop per byte staged (opt-in via force_tile, see launch())
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   // 2 waves per SIMD = two 4-wave blocks (or one 8-wave block) per CU
+__device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_block) {
   constexpr int NT = 64 * WM * WN, NWAVES = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;      // 16x16 fragments per wave
   static_assert(BM % (16 * WM) == 0 && BN % (16 * WN) == 0 && (BM / 8) % NWAVES == 0 && (BN / 8) % NWAVES == 0 && (BM * 8) % NT == 0 && (BN * 8) % NT == 0, "tile/wave shape");
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   /
   // an XCD works on at once then form an ~8x8 patch that needs 8 A panels + 8 B panels (3 MB at K=768: fits the L2) instead of
   // 2-3 A panels + ALL B panels of an n-fastest walk (5+ MB: the weight matrix kept falling out to the Infinity Cache).
   const int nblk = p.tiles_m * p.tiles_n;
-  int bid = blockIdx.x % nblk;
-  const int split = blockIdx.x / nblk;
+  int bid = linear_block % nblk;
+  const int split = linear_block / nblk;
   {
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, loc = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
@@ -289,6 +289,26 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   /
   }
 }
 
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   // 2 waves per SIMD = two 4-wave blocks (or one 8-wave block) per CU
+  gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT>(p, blockIdx.x);
+}
+
+// Grouped launch: up to 8 independent problems of the same kind in ONE grid (block ranges start at multiples of 8 so the XCD-aware
+// tile remap still sees its hardware XCD).  Used for the four weight-gradient GEMMs of an encoder layer: 36+108+144+144 = 432 tiles
+// fill the 512 block slots in a single round, so no split-K (and no partial-sum reduction pass) is needed at all.
+struct GroupArgs { GemmArgs a[8]; int start[9]; int count; };
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupArgs g) {
+  int prob = 0;
+#pragma unroll
+  for (int q = 1; q < 8; ++q)
+    if (q < g.count && (int)blockIdx.x >= g.start[q]) prob = q;
+  const int local = blockIdx.x - g.start[prob];
+  if (local >= g.a[prob].tiles_m * g.a[prob].tiles_n) return;     // padding block
+  gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT>(g.a[prob], local);
+}
+
 // C[m,n] += sum_s ws[s][m,n]; bias_grad[m] += sum_s wsb[s][m]   (fixed summation order: reproducible)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int S, int M, int N, float* C, int64_t ldc, float* bias_grad) {
   const int64_t mn4 = (int64_t)M * N / 4;
@@ -387,6 +407,42 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
 }
 
 }  // namespace
+
+extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream) {
+  SAM_REQUIRE(descs && count >= 1 && count <= 8, "sam_gemm_bf16_grouped: 1..8 problems");
+  GroupArgs g = {};
+  g.count = count;
+  int total = 0;
+  for (int q = 0; q < count; ++q) {
+    const sam_gemm_desc* d = descs + q;
+    SAM_REQUIRE(!d->a_kcontig && !d->b_kcontig && d->c_is_f32 && d->epilogue == SAM_EPI_NONE && (d->split_k == 0 || d->split_k == 1),
+                "sam_gemm_bf16_grouped: problem %d is not a plain fp32 wgrad-layout GEMM", q);
+    SAM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->A && d->B && d->C, "sam_gemm_bf16_grouped: problem %d is empty", q);
+    SAM_REQUIRE(d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "sam_gemm_bf16_grouped: problem %d: M, N, lda, ldb must be multiples of 8", q);
+    SAM_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0) && ((uintptr_t)d->C % 16 == 0), "sam_gemm_bf16_grouped: problem %d: operands must be 16-byte aligned", q);
+    GemmArgs& a = g.a[q];
+    a.M = d->M; a.N = d->N; a.K = d->K;
+    a.A = (const bf16_t*)d->A; a.lda = d->lda; a.B = (const bf16_t*)d->B; a.ldb = d->ldb; a.C = d->C; a.ldc = d->ldc;
+    a.accumulate = d->accumulate ? 1 : 0;
+    a.inv_keep = 1.0f;
+    a.tiles_m = (d->M + 127) / 128; a.tiles_n = (d->N + 127) / 128;
+    a.group_m = 1;
+    a.split_k = 1;
+    a.bias_grad = d->bias_grad;
+    g.start[q] = total;
+    total += (a.tiles_m * a.tiles_n + 7) / 8 * 8;     // keep every problem's first block on XCD 0
+  }
+  g.start[count] = total;
+  constexpr size_t LDS = (size_t)2 * (128 + 128) * BK * 2;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    once = true;
+  }
+  gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float><<<dim3(total), dim3(256), LDS, (hipStream_t)stream>>>(g);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
 
 extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream) {
   SAM_REQUIRE(ws && C && split_k >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0, "sam_gemm_splitk_reduce: bad arguments");

@@ -269,3 +269,19 @@ def spatial_relation_tensor(boxes, context=3, distance_threshold=0.5):
     out = torch.empty((b, n, n, 12), dtype=torch.int8, device=boxes.device)
     capi.call("sam_spatial_relation_tensor", capi.ptr(boxes), b, n, int(context), float(distance_threshold), capi.ptr(out), capi.stream_handle())
     return out
+
+
+def wgrad_grouped(jobs):
+    """jobs: list of (dy [R,M] bf16, x [R,N] bf16, dW fp32 [M,N] view, dbias fp32 [M] or None).  dW += dy^T x (and dbias += colsum(dy))
+    for all jobs in ONE launch (sam_gemm_bf16_grouped)."""
+    n = len(jobs)
+    arr = (capi.GemmDesc * n)()
+    flops = 0.0
+    for d, (dy, x, dw, db) in zip(arr, jobs):
+        d.M, d.N, d.K = dy.shape[1], x.shape[1], dy.shape[0]
+        d.a_kcontig = d.b_kcontig = 0
+        d.c_is_f32, d.accumulate, d.epilogue = 1, 1, capi.EPI_NONE
+        d.A, d.lda, d.B, d.ldb, d.C, d.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
+        d.bias_grad = _dp(db)
+        flops += 2.0 * d.M * d.N * d.K
+    capi.call("sam_gemm_bf16_grouped", arr, n, capi.stream_handle(), meta=dict(kernel="gemm_grouped_wgrad", flops=flops, shape=(n,)))

@@ -137,6 +137,27 @@ def test_both_tile_configs_all_layouts(tile):
     assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
 
 
+def test_grouped_wgrad_matches_individual():
+    ops, capi = _mods()
+    R = 1456
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    jobs, refs = [], []
+    for j, (m, n) in enumerate(shapes):
+        dy, x = rnd((R, m), 30 + j), rnd((R, n), 40 + j)
+        base = torch.randn(m, n, generator=torch.Generator().manual_seed(50 + j))
+        dw = base.clone().cuda()
+        db = torch.full((m,), 0.25, device="cuda") if j % 2 else None
+        jobs.append((dy.cuda(), x.cuda(), dw, db))
+        refs.append((base + dy.float().t() @ x.float(), None if db is None else 0.25 + dy.float().sum(0)))
+    ops.wgrad_grouped(jobs)
+    for (dy, x, dw, db), (rw, rb) in zip(jobs, refs):
+        assert_close_bf16(dw, rw, ulps=0, name="grouped wgrad")
+        if db is not None:
+            assert_close_bf16(db, rb, ulps=0, name="grouped bias grad")
+    with pytest.raises(capi.SamHipError):
+        ops.wgrad_grouped(jobs * 3)         # more than 8 problems
+
+
 def test_strided_views_and_errors():
     ops, capi = _mods()
     big = rnd((300, 2304), 16).cuda()
