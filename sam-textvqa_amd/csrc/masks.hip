@@ -78,9 +78,20 @@ __global__ void spatial_kernel(const uint32_t* base, const int8_t* adj, int B, i
     if (zeroed) continue;
     if (rq == 1 && rk == 1) {
       const int8_t* p = adj + (((int64_t)b * n_oo + (q - T)) * n_oo + (key - T)) * R;
+      if ((R & 3) == 0) {   // dataset layout: R = 12 relation bytes per pair = 3 aligned dwords
+        const uint32_t* pw = reinterpret_cast<const uint32_t*>(p);
 #pragma unroll
-      for (int h = 0; h < 16; ++h)
-        if (h < R) sp[h] |= (p[h] != 0 ? 1u : 0u) << k;
+        for (int j = 0; j < 4; ++j)
+          if (4 * j < R) {
+            const uint32_t d = pw[j];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sp[4 * j + e] |= (((d >> (8 * e)) & 0xffu) != 0 ? 1u : 0u) << k;
+          }
+      } else {
+#pragma unroll
+        for (int h = 0; h < 16; ++h)
+          if (h < R) sp[h] |= (p[h] != 0 ? 1u : 0u) << k;
+      }
     } else {
 #pragma unroll
       for (int h = 0; h < 16; ++h) sp[h] |= 1u << k;
