@@ -426,7 +426,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     a.accumulate = d->accumulate ? 1 : 0;
     a.inv_keep = 1.0f;
     a.tiles_m = (d->M + 127) / 128; a.tiles_n = (d->N + 127) / 128;
-    a.group_m = 1;
+    { static int gm = -1; if (gm < 0) { const char* e = getenv("SAM_GEMM_GROUP_M_WGRAD"); gm = e ? atoi(e) : 0; } a.group_m = gm > 0 ? gm : 1; }
     a.split_k = 1;
     a.bias_grad = d->bias_grad;
     g.start[q] = total;
