@@ -65,6 +65,15 @@ class SamHipError(RuntimeError):
 def lib():
     global _lib
     if _lib is None:
+        # (re)build when the sources changed or the library is missing; a no-op (source hash compare) otherwise.  If that is
+        # impossible (no hipcc) and no library exists, fail: there is no fallback path.
+        try:
+            from . import _build
+            _build.build()
+        except Exception as e:
+            if not os.path.exists(LIB_PATH):
+                raise SamHipError("libsam_hip.so is missing and could not be built (%s): run `python __graft_entry__.py`; "
+                                  "there is no fallback path" % e)
         if not os.path.exists(LIB_PATH):
             raise SamHipError("libsam_hip.so not built (%s): run `python __graft_entry__.py` or "
                               "sam_textvqa_amd._build.build(); there is no fallback path" % LIB_PATH)

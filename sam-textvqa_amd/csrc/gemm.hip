@@ -413,6 +413,9 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
   GroupArgs g = {};
   g.count = count;
   int total = 0;
+  static int bm_env = -1;
+  if (bm_env < 0) { const char* e = getenv("SAM_WGRAD_TILE_M"); bm_env = e ? atoi(e) : 0; }
+  const int bm = bm_env == 256 ? 256 : 128;
   for (int q = 0; q < count; ++q) {
     const sam_gemm_desc* d = descs + q;
     SAM_REQUIRE(!d->a_kcontig && !d->b_kcontig && d->c_is_f32 && d->epilogue == SAM_EPI_NONE && (d->split_k == 0 || d->split_k == 1),
@@ -425,7 +428,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     a.A = (const bf16_t*)d->A; a.lda = d->lda; a.B = (const bf16_t*)d->B; a.ldb = d->ldb; a.C = d->C; a.ldc = d->ldc;
     a.accumulate = d->accumulate ? 1 : 0;
     a.inv_keep = 1.0f;
-    a.tiles_m = (d->M + 127) / 128; a.tiles_n = (d->N + 127) / 128;
+    a.tiles_m = (d->M + bm - 1) / bm; a.tiles_n = (d->N + 127) / 128;
     { static int gm = -1; if (gm < 0) { const char* e = getenv("SAM_GEMM_GROUP_M_WGRAD"); gm = e ? atoi(e) : 0; } a.group_m = gm > 0 ? gm : 1; }
     a.split_k = 1;
     a.bias_grad = d->bias_grad;
@@ -433,13 +436,16 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     total += (a.tiles_m * a.tiles_n + 7) / 8 * 8;     // keep every problem's first block on XCD 0
   }
   g.start[count] = total;
-  constexpr size_t LDS = (size_t)2 * (128 + 128) * BK * 2;
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<256, 128, 4, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * BK * 2);
     once = true;
   }
-  gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float><<<dim3(total), dim3(256), LDS, (hipStream_t)stream>>>(g);
+  if (bm == 256)
+    gemm_group_kernel<256, 128, 4, 2, false, false, SAM_EPI_NONE, float><<<dim3(total), dim3(512), (size_t)2 * (256 + 128) * BK * 2, (hipStream_t)stream>>>(g);
+  else
+    gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float><<<dim3(total), dim3(256), (size_t)2 * (128 + 128) * BK * 2, (hipStream_t)stream>>>(g);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
