@@ -214,3 +214,29 @@ def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
     assert list(sd["model_state_dict"]) == list(ref.state_dict())
     ref.load_state_dict(sd["model_state_dict"])                   # a checkpoint written here loads into the reference layout
     tr.load_model_state_dict({"module." + k: v for k, v in sd["model_state_dict"].items()})
+
+
+def test_greedy_decode_eval_matches_oracle():
+    """eval(): BOS-seeded greedy loop, 12 re-forwards (sa_m4c.py:285-302); scores close, decoded indices (argmax of near-equal
+    logits may flip under bf16) agree on the overwhelming majority of steps"""
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    shapes = (20, 100, 50, 12)
+    model, ref = _small_full_model(3, ("n", "s"), shapes)
+    bd_cpu = make_batch(3, *shapes, vocab=300, context=3, device="cpu", seed=13)
+    bd_cpu["question_indices"] = (bd_cpu["question_indices"] % 499 + 1) * bd_cpu["question_mask"]
+    ref.eval()
+    with torch.no_grad():
+        ref_bd = clone_batch(bd_cpu)
+        ref_scores = ref(ref_bd)["textvqa_scores"]
+    model.cuda().eval()
+    prepare(model)
+    bd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd_cpu.items()}
+    with torch.no_grad():
+        scores = model(bd)["textvqa_scores"]
+    assert (bd["train_prev_inds"][:, 0] == 1).all()                     # BOS
+    agree = (bd["train_prev_inds"].cpu() == ref_bd["train_prev_inds"]).float().mean().item()
+    assert agree >= 0.8, agree
+    same = (bd["train_prev_inds"].cpu() == ref_bd["train_prev_inds"]).all(dim=1)       # samples whose whole decode path agrees
+    if same.any():
+        assert rel_err(scores[same.cuda()], ref_scores[same]) < 0.05
