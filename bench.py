@@ -25,13 +25,23 @@ PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec
 
 
-def build_model(context, layers, vocab, seed=0):
+def build_model(context, layers, vocab, shape=(20, 100, 50, 12), seed=0):
     from sam_textvqa_amd import modules as M
     from sam_textvqa_amd import synthetic as S
     torch.manual_seed(seed)                                  # identical replicas on every rank
-    mcfg = M.BertConfig.from_dict(S.mmt_config_dict(context, layers))
+    T, n_obj, n_ocr, n_dec = shape
+    mcfg = M.BertConfig.from_dict(S.mmt_config_dict(context, layers, n_dec=n_dec, T=T, n_obj=n_obj, n_ocr=n_ocr))
     tcfg = M.BertConfig.from_dict(S.text_bert_config_dict())
     return M.SAM4C(mcfg, tcfg, num_answers=vocab, bos_idx=1)
+
+
+def train_gflop(shape, n_layers, vocab, D=768):
+    """algorithmic training GFLOP per sample (3 x forward), SURVEY.md §8(d): F_layer(N) = 24 N D^2 + 4 N^2 D"""
+    T, n_obj, n_ocr, n_dec = shape
+    N = T + n_obj + n_ocr + n_dec
+    f_layer = lambda n: 24.0 * n * D * D + 4.0 * n * n * D
+    fwd = n_layers * f_layer(N) + 3 * f_layer(T) + 2.0 * n_obj * 2048 * D + 2.0 * n_ocr * 3002 * D + 2.0 * n_dec * D * vocab + 2.0 * (n_dec + n_ocr) * D * D
+    return 3.0 * fwd / 1e9
 
 
 def profile_step(trainer, batch):
@@ -140,6 +150,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
     ap.add_argument("--context", type=int, default=3)
     ap.add_argument("--vocab", type=int, default=5000)
+    ap.add_argument("--shape", default="c3", choices=["c3", "stress"],
+                    help="c3: T=20,100 obj,50 OCR,12 dec, layers n,n,s,s,s,s (BASELINE configs 1-4); stress: 200 obj,100 OCR,30 dec, 12 layers (config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -151,10 +163,12 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     dev = torch.device("cuda", local)
-    layers = ("n", "n", "s", "s", "s", "s")
-    model = build_model(args.context, layers, args.vocab)
+    from sam_textvqa_amd.synthetic import SHAPES
+    shape = SHAPES[args.shape]
+    layers = ("n", "n", "s", "s", "s", "s") if args.shape == "c3" else ("n", "n") + ("s",) * 10
+    model = build_model(args.context, layers, args.vocab, shape)
     trainer = Trainer(model, seed=1234 + rank)
-    batch = make_batch(args.batch, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
+    batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
 
     for _ in range(args.warmup):
         loss = trainer.step(clone_batch(batch))
@@ -184,13 +198,13 @@ def main():
         "metric": "training samples/sec, SA-M4C c=%d synthetic batch" % args.context, "value": round(gb * args.steps / dt, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": "SA-M4C c=%d full train step (fwd + masked BCE + bwd + clip 0.25 + Adam + LR), T=20 + 100 obj + 50 OCR + 12 dec = 182 tokens, "
-                               "768-d, 12 heads, MMT n,n,s,s,s,s + TextBert 3 layers + input encoders + classifier(V=%d)/pointer net, dropout 0.1 on, "
-                               "bf16 MFMA compute, fp32 master weights/Adam" % (args.context, args.vocab),
-                   "global_batch": gb, "per_gpu_batch": args.batch, "seq_len": 182, "parallelism": "dp%d" % world},
+        "config": {"workload": "SA-M4C c=%d full train step (fwd + masked BCE + bwd + clip 0.25 + Adam + LR), T=%d + %d obj + %d OCR + %d dec = %d tokens, "
+                               "768-d, 12 heads, MMT %s + TextBert 3 layers + input encoders + classifier(V=%d)/pointer net, dropout 0.1 on, "
+                               "bf16 MFMA compute, fp32 master weights/Adam" % ((args.context,) + shape + (sum(shape), ",".join(layers), args.vocab)),
+                   "global_batch": gb, "per_gpu_batch": args.batch, "seq_len": sum(shape), "parallelism": "dp%d" % world},
         "final_loss": final_loss,
-        "train_gflop_per_sample": 52.9,
-        "mfma_fraction_whole_step": round(gb * args.steps / dt * 52.9e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+        "train_gflop_per_sample": round(train_gflop(shape, len(layers), args.vocab), 2),
+        "mfma_fraction_whole_step": round(gb * args.steps / dt * train_gflop(shape, len(layers), args.vocab) * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
     if world == 1 and not args.no_roofline:
         roof, table = roofline_from(profile_step(trainer, batch))
