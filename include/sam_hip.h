@@ -56,7 +56,12 @@ int sam_spatial_relation_tensor(const double* boxes, int B, int N, int context, 
 int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
                  int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
                  uint32_t* keep, void* stream);
-/* autograd of the above: dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
+/* inference variant for the greedy decoding loop (sam/sa_m4c.py:285-302): only query rows >= q_begin (rounded down to a multiple of
+ * 16) are computed, against the keys/values of ALL rows of qkv; other rows of out / lse2 are left untouched.  With the prefix-LM mask
+ * encoder rows never see decoder keys, so their q/k/v (and outputs) are step-invariant and stay cached in qkv / out. */
+int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                      int head_dim, float scale, int q_begin, void* out, float* lse2, void* stream);
+/* autograd of sam_attn_fwd: dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
 int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow, int64_t allow_stride_b,
                  int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim, float scale, float p_drop,
                  void* dqkv, float* delta_ws, void* stream);

@@ -27,6 +27,7 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)
 # name -> argtypes (all return int status except where noted)
 SIGNATURES = {
     "sam_attn_fwd": [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _f, _u64, _u64, _vp, _vp, _vp, _vp],
+    "sam_attn_fwd_rows": [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "sam_attn_bwd": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "sam_attn_words_per_row": [_i],
     "sam_mask_bits_prefix_lm": [_vp, _i, _i, _i, _i, _vp, _vp],

@@ -73,7 +73,7 @@ struct AttnArgs {
   float* lse2_w;          // [B, H, N] fwd writes: log2-domain logsumexp of scale*s (+inf for dead rows)
   const float* lse2;
   float* delta;           // [B, H, N] bwd workspace: sum_k P*dP per query row
-  int B, N, H, NW, nkt;
+  int B, N, H, NW, nkt, q_begin;   // q_begin: first query row to compute (forward only; rounded down to a 16-row tile)
   float scale, scale_log2, p_drop, inv_keep;
   unsigned thr16, seed_lo, seed_hi, off_lo, off_hi;
 };
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnAr
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  for (int mt = wave; mt * 16 < N; mt += 4) {
+  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += 4) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     bf16x8 qf[2];
 #pragma unroll
@@ -412,16 +412,32 @@ extern "C" int sam_attn_words_per_row(int N) {
   return nkt > 0 ? nkt / 2 : -1;
 }
 
+static int attn_fwd_impl(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                         int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, int q_begin, void* out, float* lse2,
+                         uint32_t* keep, void* stream);
+
 extern "C" int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
                             int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
                             uint32_t* keep, void* stream) {
+  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, p_drop, seed, offset, 0, out, lse2, keep, stream);
+}
+
+extern "C" int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                                 int head_dim, float scale, int q_begin, void* out, float* lse2, void* stream) {
+  SAM_REQUIRE(q_begin >= 0 && q_begin < N, "sam_attn_fwd_rows: q_begin=%d outside [0,%d)", q_begin, N);
+  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, 0.f, 0, 0, q_begin, out, lse2, nullptr, stream);
+}
+
+static int attn_fwd_impl(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                         int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, int q_begin, void* out, float* lse2,
+                         uint32_t* keep, void* stream) {
   AttnArgs a = {};
   int rc = fill_common(a, B, N, H, head_dim, scale, p_drop);
   if (rc) return rc;
   SAM_REQUIRE(qkv && allow && out && lse2, "sam_attn_fwd: null pointer");
   SAM_REQUIRE(a.thr16 == 0 || keep, "sam_attn_fwd: dropout needs a keep-bits buffer");
   a.qkv = (const bf16_t*)qkv; a.out_w = (bf16_t*)out; a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h;
-  a.lse2_w = lse2; a.keep_w = keep;
+  a.lse2_w = lse2; a.keep_w = keep; a.q_begin = q_begin;
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.off_lo = (unsigned)offset; a.off_hi = (unsigned)(offset >> 32);
   hipStream_t st = (hipStream_t)stream;
   switch (a.nkt) {

@@ -13,8 +13,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, PtrScoresFn, embedding, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, PtrScoresFn, _fused_qkv, _w, embedding, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -256,6 +257,42 @@ class _FusedLayer(_HipModule):
         return (y.view(b, n, -1).to(hidden_states.dtype),)
 
 
+# ------------------------------------------------------------------------------------------ inference (greedy decoding)
+def _layer_tail(layer, ctx, x):
+    """everything of an encoder layer after the attention core, eval mode (no dropout), on a row subset: O-proj + LN, FFN + LN"""
+    so, inter, out = layer.attention.output, layer.intermediate, layer.output
+    z1 = ops.gemm(ctx, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x)
+    a, _, _ = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
+    pre = torch.empty((x.shape[0], inter.dense.weight.shape[0]), dtype=BF16, device=x.device)
+    h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU, bias=inter.dense.bias, aux_out=pre)
+    z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a)
+    return ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)[0]
+
+
+def layer_infer_full(layer, x, allow, batch):
+    """eval-mode layer forward over all rows that also returns what the decoding cache keeps: (y, qkv [B*N,3D], ctx [B*N,D], lse2)"""
+    att = layer.attention.self
+    wqkv, bqkv, _, _ = _fused_qkv(att)
+    qkv = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
+    ctx, lse2, _ = ops.attn_fwd(qkv, allow, batch, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size))
+    return _layer_tail(layer, ctx, x), qkv, ctx, lse2
+
+
+def layer_infer_decode(layer, x_dec, cache, allow, batch, n, n_dec):
+    """re-run one layer for the decoder rows only (x_dec [B*n_dec, D]) against the cached keys/values of the other rows.
+    Under the prefix-LM mask (sa_m4c.py:834-844) no encoder row sees a decoder key, so every non-decoder row of every layer is
+    identical in all 12 greedy steps of sa_m4c.py:294-302: only B*n_dec of B*N rows are recomputed per step."""
+    att = layer.attention.self
+    wqkv, bqkv, _, _ = _fused_qkv(att)
+    qkv, ctx, lse2 = cache
+    d3 = qkv.shape[1]
+    qkv_dec = ops.gemm(x_dec, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
+    qkv.view(batch, n, d3)[:, n - n_dec:] = qkv_dec.view(batch, n_dec, d3)
+    ops.attn_fwd_rows(qkv, allow, batch, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), n - n_dec, ctx, lse2)
+    ctx_dec = ctx.view(batch, n, -1)[:, n - n_dec:].reshape(batch * n_dec, -1)
+    return _layer_tail(layer, ctx_dec, x_dec)
+
+
 class BertLayer(_FusedLayer):
     """pytorch-transformers BertLayer ('n' layers, sa_m4c.py:718-722,741-743; TextBert layers)"""
 
@@ -383,6 +420,33 @@ class BertSpatialEncoder(_HipModule):
             outputs += (all_hidden + (hidden_states,),)
         return outputs
 
+    def _layer_plan(self, allow, batch_dict, n_txt):
+        """[(layer, allow bits)] in execution order"""
+        normal, spatial, plan = iter(self.normal_layers), iter(self.spatial_layers), []
+        for kind, mix in zip(self.layer_type_list, self.mix_list):
+            if kind == "n":
+                plan.append((next(normal), allow.base))
+            elif kind == "s":
+                layer = next(spatial)
+                adj = batch_dict["spatial_adj_matrices"][self.matrix_type_map[mix]]
+                plan.append((layer, layer.attention.self._allow_bits(allow, adj)))
+            else:
+                raise ValueError
+        return plan
+
+    def infer_full(self, x, allow, batch_dict, batch):
+        """eval forward over all rows; returns (hidden [B*N,D], per-layer decoding caches)"""
+        caches = []
+        for layer, bits in self._layer_plan(allow, batch_dict, None):
+            x, qkv, ctx, lse2 = layer_infer_full(layer, x, bits, batch)
+            caches.append((qkv, ctx, lse2))
+        return x, caches
+
+    def infer_decode(self, x_dec, allow, batch_dict, batch, n, n_dec, caches):
+        for (layer, bits), cache in zip(self._layer_plan(allow, batch_dict, None), caches):
+            x_dec = layer_infer_decode(layer, x_dec, cache, bits, batch, n, n_dec)
+        return x_dec
+
 
 class PrevPredEmbeddings(_HipModule):
     """sam/sa_m4c.py:900-948 — without materialising the [B, V+n_ocr, D] table (15.5 MB/sample upstream): the two
@@ -437,7 +501,26 @@ class MMT(_HipModule):
         n_dec = dec_emb.size(1)
         key_valid = torch.cat([batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"]], dim=1)
         allow = AllowBits(ops.mask_bits_prefix_lm(key_valid.to(device=x.device, dtype=torch.uint8).contiguous(), n_dec))
+        cache = batch_dict.get("_sam_decode_cache")
+        if cache is not None and not torch.is_grad_enabled():
+            return self._forward_cached(batch_dict, cache, x, allow, n_txt, n_obj, n_ocr, n_dec)
         seq = self.encoder(x, allow, batch_dict, head_mask=[None] * self.config.num_hidden_layers)[0]
+        ocr0 = n_txt + n_obj
+        return {"mmt_seq_output": seq, "mmt_txt_output": seq[:, :n_txt], "mmt_ocr_output": seq[:, ocr0: ocr0 + n_ocr],
+                "mmt_dec_output": seq[:, -n_dec:]}
+
+    def _forward_cached(self, batch_dict, cache, x, allow, n_txt, n_obj, n_ocr, n_dec):
+        """greedy decoding with encoder-row caching.  First call: full eval pass that records each layer's
+        q|k|v and attention output; later calls: only the n_dec decoder rows go through the layers."""
+        b, n, d = x.shape
+        if "layers" not in cache:
+            seq2d, cache["layers"] = self.encoder.infer_full(x.reshape(b * n, d).contiguous(), allow, batch_dict, b)
+            cache["seq"] = seq2d.view(b, n, d)
+        else:
+            x_dec = x[:, n - n_dec:].reshape(b * n_dec, d).contiguous()
+            y_dec = self.encoder.infer_decode(x_dec, allow, batch_dict, b, n, n_dec, cache["layers"])
+            cache["seq"][:, n - n_dec:] = y_dec.view(b, n_dec, d)
+        seq = cache["seq"]
         ocr0 = n_txt + n_obj
         return {"mmt_seq_output": seq, "mmt_txt_output": seq[:, :n_txt], "mmt_ocr_output": seq[:, ocr0: ocr0 + n_ocr],
                 "mmt_dec_output": seq[:, -n_dec:]}
@@ -498,6 +581,7 @@ class SAM4C(_HipModule):
         n_out = num_answers if num_answers is not None else len(registry.answer_vocab)
         self.bos_idx = bos_idx if bos_idx is not None else registry.BOS_IDX
         self.classifier = nn.Linear(h, n_out)
+        self.decode_cache = True      # eval-mode greedy loop re-runs only the decoder rows (set False for the reference's 12 full passes)
 
     def _forward_obj_encoding(self, bd):
         feat = bd["pad_obj_features"]
@@ -520,8 +604,12 @@ class SAM4C(_HipModule):
         bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)
 
     def _forward_mmt(self, bd):
-        t = self.text_bert(bd)
-        bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+        cache = bd.get("_sam_decode_cache")
+        if cache is None or "text_bert_emb" not in cache:
+            t = self.text_bert(bd)
+            bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+            if cache is not None:
+                cache["text_bert_emb"] = bd["text_bert_emb"]      # question encoding does not depend on the decoding step
         bd.update(self.mmt(bd, fixed_ans_emb=self.classifier.weight))
 
     def _forward_output(self, bd):
@@ -543,10 +631,13 @@ class SAM4C(_HipModule):
             steps = batch_dict["train_prev_inds"].size(1)
             batch_dict["train_prev_inds"] = torch.zeros_like(batch_dict["train_prev_inds"])
             batch_dict["train_prev_inds"][:, 0] = self.bos_idx
+            if self.decode_cache and not torch.is_grad_enabled():
+                batch_dict["_sam_decode_cache"] = {}      # encoder rows are step-invariant: computed once, decoder rows 12x
             for _ in range(steps):
                 self._forward_mmt(batch_dict)
                 self._forward_output(batch_dict)
                 batch_dict["train_prev_inds"][:, 1:] = batch_dict["scores"].argmax(dim=-1)[:, :-1]
+            batch_dict.pop("_sam_decode_cache", None)
         return {"textvqa_scores": batch_dict["scores"]}
 
     def get_optimizer_parameters(self, base_lr):

@@ -86,6 +86,18 @@ def attn_fwd(qkv, allow, batch, n_heads, scale, p_drop=0.0, seed=0, offset=0):
     return out, lse2, keep
 
 
+def attn_fwd_rows(qkv, allow, batch, n_heads, scale, q_begin, out, lse2):
+    """inference: recompute only query rows >= q_begin of `out` (bf16 [B*N, H*64], updated in place) against all keys of qkv"""
+    _chk(qkv, BF16, "qkv"); _chk(allow, torch.int32, "allow"); _chk(out, BF16, "out")
+    rows, three_d = qkv.shape
+    n = rows // batch
+    d_model = three_d // 3
+    sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    capi.call("sam_attn_fwd_rows", capi.ptr(qkv), capi.ptr(allow), allow.stride(0), sh, batch, n, n_heads, d_model // n_heads, float(scale), int(q_begin),
+              capi.ptr(out), capi.ptr(lse2), capi.stream_handle())
+    return out
+
+
 def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0):
     """-> dqkv bf16 [B*N, 3*H*64]."""
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv")

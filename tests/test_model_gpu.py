@@ -240,3 +240,23 @@ def test_greedy_decode_eval_matches_oracle():
     same = (bd["train_prev_inds"].cpu() == ref_bd["train_prev_inds"]).all(dim=1)       # samples whose whole decode path agrees
     if same.any():
         assert rel_err(scores[same.cuda()], ref_scores[same]) < 0.05
+
+
+def test_cached_greedy_decode_equals_full_recompute():
+    """encoder-row caching (12x fewer rows per greedy step) must give the same scores / indices as 12 full forwards"""
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import make_batch
+    shapes = (20, 100, 50, 12)
+    model, _ = _small_full_model(3, ("n", "s", "s"), shapes)
+    model.cuda().eval()
+    prepare(model)
+    outs = []
+    for cached in (False, True):
+        model.decode_cache = cached
+        bd = make_batch(3, *shapes, vocab=300, context=3, device="cuda", seed=17)
+        bd["question_indices"] = (bd["question_indices"] % 499 + 1) * bd["question_mask"]
+        with torch.no_grad():
+            outs.append((model(bd)["textvqa_scores"].float().cpu(), bd["train_prev_inds"].cpu(), bd["mmt_seq_output"].float().cpu()))
+        assert "_sam_decode_cache" not in bd
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])      # same kernels, same k order: bit-identical
