@@ -111,7 +111,15 @@ def roofline_from(agg):
         ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
         roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
                     traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
-    return roof, table[:12]
+    extra = {}
+    for key in ("attn_fwd", "attn_bwd(dq+dkdv)"):     # the north-star kernel: HBM-bound, reported next to the dominant (GEMM) kernel
+        if key in agg and agg[key]["bytes"]:
+            a = agg[key]
+            ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            extra[key] = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
+                              traffic=pmc_traffic(key), avg_launch_us=round(1e3 * a["ms"] / a["calls"], 2), launches_per_step=a["calls"],
+                              bytes_per_launch=a["bytes"] / a["calls"])
+    return roof, table[:12], extra
 
 
 def cpu_baseline(context, layers, vocab, budget_s=25.0):
@@ -207,8 +215,9 @@ def main():
         "mfma_fraction_whole_step": round(gb * args.steps / dt * train_gflop(shape, len(layers), args.vocab) * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
     if world == 1 and not args.no_roofline:
-        roof, table = roofline_from(profile_step(trainer, batch))
+        roof, table, extra = roofline_from(profile_step(trainer, batch))
         res["roofline"] = roof
+        res["roofline_attention"] = extra
         res["kernels"] = table
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.context, layers, args.vocab)
