@@ -142,6 +142,33 @@ int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const v
  * are skipped.  fp32 atomics (rows may repeat). */
 int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream);
 
+/* ---- front end: feature normalisation + packing, embedding sums, previous-prediction gather (csrc/embed.hip) ----
+ * sam_l2norm_pack_bf16: F.normalize(x, dim=-1) (x / max(||x||_2, eps); normalize = 0: plain cast) of fp32 rows [M, D], rounded to bf16 and
+ *   written at column col0 of out [M, ldo]; columns [col0 + D, zero_upto) are zeroed.  Replaces the normalize / cat chain of
+ *   SAM4C.forward_obj_encoding / forward_ocr_encoding, sam/sa_m4c.py:217-253: the OCR row (FastText 300 | PHOC 604 | FRCN 2048 | 50 zeros)
+ *   is packed by three calls into the K-padded GEMM operand.  D, ldx, ldo, col0 multiples of 4.
+ * sam_embed_sum_fwd: out[r,:] = table[ids[r],:] (bf16 rows; table may be NULL) + pos[r % S,:] + tt[type_ids[r],:] (type_ids NULL = type 0), fp32 out
+ *   = the LayerNorm input of BertEmbeddings.forward (pytorch-transformers, used by TextBert sam/sa_m4c.py:377) and of the position/type
+ *   half of PrevPredEmbeddings.forward, sam/sa_m4c.py:932-945.
+ * sam_embed_sum_bwd: d_pos[s,:] += sum_b d[b*S+s,:];  d_tt[t,:] += sum_{r: type[r]==t} d[r,:]  (d bf16 [R, D]; deterministic; n_types <= 4;
+ *   ws: sam_embed_sum_bwd_ws_bytes).  The table gradient is sam_embedding_bwd.
+ * sam_gather2_add_fwd: out[b,s,:] = (ind < V ? ans[ind,:] : ocr[b*n_ocr + ind - V,:]) + dropout(emb[b,s,:])  -- _batch_gather over
+ *   cat([ans_emb, ocr_emb]) + the embedding sum of PrevPredEmbeddings.forward, sam/sa_m4c.py:921-948, without the [B, V+n_ocr, D] table.
+ *   ans bf16 [V, D], ocr bf16 [B*n_ocr, D], inds int64 [B, S] (clamped to [0, V+n_ocr)), emb bf16 [B*S, D] or NULL; Philox dropout on emb.
+ * sam_gather2_add_bwd: d_ans[ind,:] += dy / d_ocr[...] += dy (fp32 atomics into pre-zeroed buffers: indices repeat);
+ *   d_emb (bf16, may be NULL) = the same dropout mask applied to dy. */
+int sam_l2norm_pack_bf16(const float* x, int64_t ldx, int M, int D, int normalize, float eps, void* out, int64_t ldo, int col0, int zero_upto,
+                         void* stream);
+int sam_embed_sum_fwd(const void* table, int64_t ld_table, const int64_t* ids, int table_rows, const float* pos, int64_t ld_pos, int S,
+                      const float* tt, int64_t ld_tt, const uint8_t* type_ids, int n_types, int R, int D, float* out, int64_t ldo, void* stream);
+int64_t sam_embed_sum_bwd_ws_bytes(int S, int n_types, int D);
+int sam_embed_sum_bwd(const void* d, int64_t ldd, int R, int D, int S, const uint8_t* type_ids, int n_types, float* d_pos, int64_t ld_pos,
+                      float* d_tt, int64_t ld_tt, float* ws, void* stream);
+int sam_gather2_add_fwd(const void* ans, int64_t ld_ans, int V, const void* ocr, int64_t ld_ocr, int n_ocr, const int64_t* inds, int B, int S, int D,
+                        const void* emb, int64_t ld_emb, float p_drop, uint64_t seed, uint64_t offset, void* out, int64_t ldo, void* stream);
+int sam_gather2_add_bwd(const void* dy, int64_t ldd, int V, int n_ocr, const int64_t* inds, int B, int S, int D, float* d_ans, int64_t ld_dans,
+                        float* d_ocr, int64_t ld_docr, float p_drop, uint64_t seed, uint64_t offset, void* d_emb, int64_t ld_demb, void* stream);
+
 /* ---- optimizer step over ONE flat fp32 parameter buffer: clip_grad_norm_ + Adam, train.py:139-142, task_utils.py:33-57 ----
  * sam_sumsq_f32: out[0] = sum g^2 (deterministic two-stage; every data-parallel rank gets the identical value).
  * sam_adam_step: torch.optim.Adam semantics (bias-corrected, eps outside the sqrt); per-segment learning rates

@@ -48,13 +48,19 @@ SIGNATURES = {
     "sam_ptr_scores_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i64, _i64, _vp],
     "sam_ptr_scores_bwd": [_vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "sam_embedding_bwd": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
+    "sam_l2norm_pack_bf16": [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _i, _vp],
+    "sam_embed_sum_fwd": [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _vp],
+    "sam_embed_sum_bwd_ws_bytes": [_i, _i, _i],
+    "sam_embed_sum_bwd": [_vp, _i64, _i, _i, _i, _vp, _i, _vp, _i64, _vp, _i64, _vp, _vp],
+    "sam_gather2_add_fwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _f, _u64, _u64, _vp, _i64, _vp],
+    "sam_gather2_add_bwd": [_vp, _i64, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _i64, _f, _u64, _u64, _vp, _i64, _vp],
     "sam_sumsq_ws_bytes": [],
     "sam_sumsq_f32": [_vp, _i64, _vp, _vp, _vp],
     "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
 }
-NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes"}
-RET_I64 = {"sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes"}
+NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+RET_I64 = {"sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 
 _lib = None
 

@@ -85,9 +85,10 @@ class LinearFn(Function):
         wv, _, bv, _, n_pad, k_pad = _padded_views(weight, bias)
         n, k = weight.shape
         x2 = x.reshape(-1, x.shape[-1])
-        if x2.shape[1] != k:
+        pre_padded = x2.shape[1] == k_pad           # caller already laid the operand out K-padded with zero tail columns (ops.l2norm_pack)
+        if x2.shape[1] != k and not pre_padded:
             raise capi.SamHipError("LinearFn: input width %d != in_features %d" % (x2.shape[1], k))
-        if k_pad != k or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.dtype != BF16 or x2.data_ptr() % 16:
+        if (k_pad != k and not pre_padded) or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.dtype != BF16 or x2.data_ptr() % 16:
             xp = torch.zeros((x2.shape[0], k_pad), dtype=BF16, device=x.device)   # zero-padded K (e.g. 3002 -> 3008, 4 -> 8)
             xp[:, :k] = x2
             x2 = xp
@@ -110,7 +111,7 @@ class LinearFn(Function):
         ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)   # dW += dy^T x ; db += colsum(dy)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy2, wv, b_kcontig=False)[:, :k]                                   # dx = dy W
+            dx = ops.gemm(dy2, wv, b_kcontig=False)[:, :ctx.in_shape[-1]]                    # dx = dy W
             dx = dx.reshape(ctx.in_shape).to(ctx.in_dtype)
         return dx, None, None, None
 
@@ -167,6 +168,55 @@ class EmbeddingFn(Function):
 
 def embedding(idx, emb):
     return EmbeddingFn.apply(idx, emb.weight, -1 if emb.padding_idx is None else emb.padding_idx)
+
+
+class EmbedLayerNormFn(Function):
+    """LN(table[ids] + pos[r % seq] + tt[type_ids[r]]) -> bf16 [rows, D]: BertEmbeddings.forward up to the dropout (pytorch-transformers;
+    TextBert, sam/sa_m4c.py:377) and the position / token-type half of PrevPredEmbeddings.forward (sam/sa_m4c.py:932-945; table = None).
+    Two launches forward, three or four backward; the four parameter gradients go straight into the flat gradient buffer."""
+
+    @staticmethod
+    def forward(ctx, anchor, ids, table_w, pos_w, tt_w, type_ids, rows, seq, ln, padding_idx):
+        ids = None if ids is None else ids.reshape(-1).contiguous()
+        e = ops.embed_sum_fwd(pos_w.data, tt_w.data, rows, seq, table=None if table_w is None else _w(table_w), ids=ids, type_ids=type_ids)
+        y, mean, rstd = ops.layernorm_fwd(e, ln.weight, ln.bias, ln.variance_epsilon)
+        ctx.save_for_backward(e, mean, rstd, ids, type_ids)
+        ctx.params, ctx.seq, ctx.padding_idx = (table_w, pos_w, tt_w, ln), seq, padding_idx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        e, mean, rstd, ids, type_ids = ctx.saved_tensors
+        table_w, pos_w, tt_w, ln = ctx.params
+        if dy.dtype != BF16 or not dy.is_contiguous():
+            dy = dy.to(BF16).contiguous()
+        d_e, _ = ops.layernorm_bwd(dy, e, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
+        ops.embed_sum_bwd(d_e, ctx.seq, pos_w.grad, tt_w.grad, type_ids, n_types=1 if type_ids is None else min(4, tt_w.shape[0]))
+        if table_w is not None:
+            ops.embedding_bwd(d_e, ids, table_w.grad, ctx.padding_idx)
+        return (None,) * 10
+
+
+class PrevPredGatherFn(Function):
+    """(ind < V ? ans[ind] : ocr[b, ind - V]) + dropout(emb): _batch_gather over cat([ans_emb, ocr_emb]) and the final sum of
+    PrevPredEmbeddings.forward, sam/sa_m4c.py:921-948, one launch each way (the reference materialises a [B, V + n_ocr, D] table)."""
+
+    @staticmethod
+    def forward(ctx, ans, ocr2d, emb, inds, n_ocr, p_drop):
+        ctx.seed = dropout_clock.next()
+        ctx.cfg = (ans.shape[0], n_ocr, p_drop)
+        inds = inds.contiguous()
+        ctx.save_for_backward(inds)
+        return ops.gather2_add_fwd(ans.contiguous(), ocr2d.contiguous(), inds, n_ocr, emb.contiguous(), p_drop, *ctx.seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (inds,) = ctx.saved_tensors
+        v, n_ocr, p_drop = ctx.cfg
+        if dy.dtype != BF16 or not dy.is_contiguous():
+            dy = dy.to(BF16).contiguous()
+        d_ans, d_ocr, d_emb = ops.gather2_add_bwd(dy, inds, v, n_ocr, ctx.needs_input_grad[2], p_drop, *ctx.seed)
+        return d_ans, d_ocr, d_emb, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ encoder layer

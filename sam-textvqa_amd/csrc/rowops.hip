@@ -14,6 +14,7 @@ namespace {
 
 constexpr int LN_PARTIAL_BLOCKS = 512;
 
+
 template <typename T> struct Ld4;
 template <> struct Ld4<bf16_t> {
   static __device__ __forceinline__ void ld(const void* p, int64_t idx, float* v) {
@@ -73,6 +74,7 @@ template <typename InT, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
                                                      const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16,
                                                      float inv_keep, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi, float* ws) {
+  constexpr int LN_ROWS = NCH <= 3 ? 3 : (NCH == 4 ? 2 : 1);  // rows a wave keeps in flight (VGPR budget: <= 256 for 2 waves/SIMD)
   __shared__ float red[4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nchunk = D >> 2;
@@ -88,51 +90,76 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
     gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
     if (c < nchunk) Ld4<float>::ld(gamma, 4 * c, gm[j]);
   }
-  for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
-    const float mu = mean[row], rs = rstd[row];
-    float xh[NCH][4], g[NCH][4];
-    float s1 = 0.f, s2 = 0.f;
+  // LN_ROWS rows per wave in flight: all their loads are issued before the first reduction, so one wave keeps LN_ROWS x 3 KB
+  // outstanding (8 waves/CU x 9 KB covers the HBM latency-bandwidth product; one row at a time reached 1.8 TB/s)
+  const int rstride = gridDim.x * 4;
+  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += rstride * LN_ROWS) {
+    float xh[LN_ROWS][NCH][4], g[LN_ROWS][NCH][4], rs[LN_ROWS], s1[LN_ROWS], s2[LN_ROWS];
+    float xv[LN_ROWS][NCH][4], dv[LN_ROWS][NCH][4], mu[LN_ROWS];
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int c = lane + 64 * j;
-      float xv[4] = {0.f, 0.f, 0.f, 0.f}, dv[4] = {0.f, 0.f, 0.f, 0.f};
-      if (c < nchunk) {
-        Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv);
-        Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv);
-      }
+    for (int i = 0; i < LN_ROWS; ++i) {
+      const int row = row0 + i * rstride;
+      const bool live = row < M;
+      mu[i] = live ? mean[row] : 0.f;
+      rs[i] = live ? rstd[row] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        xh[j][e] = c < nchunk ? (xv[e] - mu) * rs : 0.f;
-        g[j][e] = dv[e] * gm[j][e];
-        s1 += g[j][e];
-        s2 += g[j][e] * xh[j][e];
-        ag[j][e] += dv[e] * xh[j][e];
-        ab[j][e] += dv[e];
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) xv[i][j][e] = dv[i][j][e] = 0.f;
+        if (live && c < nchunk) {
+          Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv[i][j]);
+          Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv[i][j]);
+        }
       }
     }
-    s1 = wave_sum(s1) / D;
-    s2 = wave_sum(s2) / D;
 #pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-      const int c = lane + 64 * j;
-      if (c >= nchunk) continue;
-      float o[4];
+    for (int i = 0; i < LN_ROWS; ++i) {
+      const bool live = row0 + i * rstride < M;
+      float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rs * (g[j][e] - s1 - xh[j][e] * s2);
-      st4_bf16(dx, (int64_t)row * ldo + 4 * c, o);
-      if (dxd) {
-        if (thr16) {  // same (row, col/8) Philox stream as the GEMM epilogue that produced the forward mask
-          const u32x4 rn = philox4x32_10((unsigned)row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
-          const unsigned lo = (c & 1) ? rn.z : rn.x, hi = (c & 1) ? rn.w : rn.y;
-          o[0] = (lo & 0xffffu) >= thr16 ? o[0] * inv_keep : 0.f;
-          o[1] = (lo >> 16) >= thr16 ? o[1] * inv_keep : 0.f;
-          o[2] = (hi & 0xffffu) >= thr16 ? o[2] * inv_keep : 0.f;
-          o[3] = (hi >> 16) >= thr16 ? o[3] * inv_keep : 0.f;
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          xh[i][j][e] = (live && c < nchunk) ? (xv[i][j][e] - mu[i]) * rs[i] : 0.f;
+          g[i][j][e] = dv[i][j][e] * gm[j][e];
+          t1 += g[i][j][e];
+          t2 += g[i][j][e] * xh[i][j][e];
+          ag[j][e] += dv[i][j][e] * xh[i][j][e];
+          ab[j][e] += dv[i][j][e];
         }
-        st4_bf16(dxd, (int64_t)row * ldo + 4 * c, o);
       }
+      s1[i] = t1; s2[i] = t2;
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ad[j][e] += o[e];
+    for (int i = 0; i < LN_ROWS; ++i) { s1[i] = wave_sum(s1[i]) / D; s2[i] = wave_sum(s2[i]) / D; }
+#pragma unroll
+    for (int i = 0; i < LN_ROWS; ++i) {
+      const int row = row0 + i * rstride;
+      if (row >= M) continue;
+#pragma unroll
+      for (int j = 0; j < NCH; ++j) {
+        const int c = lane + 64 * j;
+        if (c >= nchunk) continue;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = rs[i] * (g[i][j][e] - s1[i] - xh[i][j][e] * s2[i]);
+        st4_bf16(dx, (int64_t)row * ldo + 4 * c, o);
+        if (dxd) {
+          if (thr16) {  // same (row, col/8) Philox stream as the GEMM epilogue that produced the forward mask
+            const u32x4 rn = philox4x32_10((unsigned)row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
+            const unsigned lo = (c & 1) ? rn.z : rn.x, hi = (c & 1) ? rn.w : rn.y;
+            o[0] = (lo & 0xffffu) >= thr16 ? o[0] * inv_keep : 0.f;
+            o[1] = (lo >> 16) >= thr16 ? o[1] * inv_keep : 0.f;
+            o[2] = (hi & 0xffffu) >= thr16 ? o[2] * inv_keep : 0.f;
+            o[3] = (hi >> 16) >= thr16 ? o[3] * inv_keep : 0.f;
+          }
+          st4_bf16(dxd, (int64_t)row * ldo + 4 * c, o);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ad[j][e] += o[e];
+      }
     }
   }
   // block reduction over the 4 waves, then one partial row per block

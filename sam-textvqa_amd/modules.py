@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, PtrScoresFn, _fused_qkv, _w, embedding, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, PrevPredGatherFn, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -345,9 +345,11 @@ class BertEmbeddings(_HipModule):
         n = input_ids.size(1)
         # positions are 0..n-1 and the token type is 0 for every token: plain slices (their backward is a batch reduction, not a
         # scatter); the word rows are gathered from the bf16 shadow table and their gradient is scattered by sam_embedding_bwd
-        e = (embedding(input_ids, self.word_embeddings).float() + self.position_embeddings.weight[:n]
-             + self.token_type_embeddings.weight[0])
-        return F.dropout(layer_norm(e, self.LayerNorm), self.dropout_p, self.training)
+        b = input_ids.size(0)
+        pad = self.word_embeddings.padding_idx
+        y = EmbedLayerNormFn.apply(self.LayerNorm.weight, input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
+                                   self.token_type_embeddings.weight, None, b * n, n, self.LayerNorm, -1 if pad is None else pad)
+        return F.dropout(y.view(b, n, -1), self.dropout_p, self.training)
 
 
 def _bert_init_weights(module, initializer_range):
@@ -469,15 +471,11 @@ class PrevPredEmbeddings(_HipModule):
         n_ans, n_ocr = ans_emb.size(0), ocr_emb.size(1)
         ans = layer_norm(ans_emb, self.ans_layer_norm)                       # [V, D] bf16
         ocr = layer_norm(ocr_emb, self.ocr_layer_norm).reshape(b * n_ocr, -1)  # [B*n_ocr, D]
-        is_ocr = prev_inds.ge(n_ans)
-        from_ans = F.embedding(prev_inds.clamp(max=n_ans - 1), ans)
-        ocr_idx = (prev_inds - n_ans).clamp(min=0) + (torch.arange(b, device=prev_inds.device) * n_ocr).unsqueeze(-1)
-        from_ocr = F.embedding(ocr_idx, ocr)
-        raw = torch.where(is_ocr.unsqueeze(-1), from_ocr, from_ans)
-        tt = self.token_type_embeddings.weight
-        emb = self.position_embeddings.weight[:s] + torch.where(is_ocr.unsqueeze(-1), tt[1], tt[0])      # [B, S, D]
-        emb = F.dropout(layer_norm(emb, self.emb_layer_norm), self.dropout_p, self.training)
-        return raw + emb
+        is_ocr = prev_inds.ge(n_ans).view(torch.uint8).reshape(-1)          # token type: 1 for copied OCR tokens, sa_m4c.py:936
+        emb = EmbedLayerNormFn.apply(self.emb_layer_norm.weight, None, None, self.position_embeddings.weight, self.token_type_embeddings.weight,
+                                     is_ocr, b * s, s, self.emb_layer_norm, -1)
+        out = PrevPredGatherFn.apply(ans, ocr, emb, prev_inds, n_ocr, self.dropout_p if self.training else 0.0)
+        return out.view(b, s, -1)
 
 
 class MMT(_HipModule):
@@ -549,6 +547,21 @@ class OcrPtrNet(_HipModule):
         return s.squeeze(1) if squeeze else s
 
 
+def _pack_features(parts, normalize, n_zero_cols):
+    """[B, n, D_i] fp32 feature blocks -> one bf16 [B, n, pad8(sum D_i + n_zero_cols)] GEMM operand: each block L2-normalised along its own
+    last dim (F.normalize, sa_m4c.py:219,232-234) and written at its column offset; trailing columns zero.  One launch per block."""
+    b, n = parts[0].shape[:2]
+    k = sum(p.shape[-1] for p in parts) + n_zero_cols
+    k_pad = (k + 7) // 8 * 8
+    out = torch.empty((b * n, k_pad), dtype=BF16, device=parts[0].device)
+    col = 0
+    for i, p in enumerate(parts):
+        last = i == len(parts) - 1
+        ops.l2norm_pack(p.reshape(b * n, p.shape[-1]).float().contiguous(), out, col, normalize, zero_upto=k_pad if last else 0)
+        col += p.shape[-1]
+    return out.view(b, n, k_pad)
+
+
 class SAM4C(_HipModule):
     """sam/sa_m4c.py:20-371 (aux heads, beam search and the fc7-finetune image encoder are out of scope: disabled /
     dead upstream)."""
@@ -584,21 +597,16 @@ class SAM4C(_HipModule):
         self.decode_cache = True      # eval-mode greedy loop re-runs only the decoder rows (set False for the reference's 12 full passes)
 
     def _forward_obj_encoding(self, bd):
-        feat = bd["pad_obj_features"]
-        if self.normalize:
-            feat = F.normalize(feat, dim=-1)
-        x = (layer_norm(linear(feat.to(BF16), self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
+        feat = _pack_features([bd["pad_obj_features"]], self.normalize, 0)
+        x = (layer_norm(linear(feat, self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
              + layer_norm(linear(bd["pad_obj_bboxes"][:, :, :-1].to(BF16), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
         bd["obj_mmt_in"] = F.dropout(x, self.obj_drop_p, self.training)
 
     def _forward_ocr_encoding(self, bd):
         ft, ph, fc = bd["ocr_fasttext"], bd["ocr_phoc"], bd["pad_ocr_features"]
         assert ft.size(-1) == 300 and ph.size(-1) == 604
-        if self.normalize:
-            ft, ph, fc = F.normalize(ft, dim=-1), F.normalize(ph, dim=-1), F.normalize(fc, dim=-1)
-        order = fc.new_zeros((ph.size(0), ph.size(1), 50))                 # legacy all-zero order vectors, sa_m4c.py:242
-        parts = [ft, ph, fc, order] if self.mmt_config.use_phoc_fasttext else [fc, order]
-        feat = torch.cat([p.to(BF16) for p in parts], dim=-1)
+        # FastText | PHOC | FRCN | 50 legacy all-zero order columns (sa_m4c.py:242), normalised and packed into the K-padded GEMM operand
+        feat = _pack_features([ft, ph, fc] if self.mmt_config.use_phoc_fasttext else [fc], self.normalize, 50)
         x = (layer_norm(linear(feat, self.linear_ocr_feat_to_mmt_in), self.ocr_feat_layer_norm)
              + layer_norm(linear(bd["pad_ocr_bboxes"][:, :, :-1].to(BF16), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
         bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)

@@ -205,6 +205,63 @@ def colsum(x, out, accumulate=True):
     return out
 
 
+# ----------------------------------------------------------------------------- front end (csrc/embed.hip)
+def l2norm_pack(x, out, col0=0, normalize=True, zero_upto=0, eps=1e-12):
+    """out[:, col0:col0+D] = bf16(F.normalize(x, dim=-1)) (normalize=False: plain cast); x fp32 [M, D]; out bf16 [M, ldo];
+    columns [col0+D, zero_upto) of out are zeroed"""
+    _chk(x, torch.float32, "x")
+    _chk(out, BF16, "out")
+    m, d = x.shape
+    if x.stride(1) != 1 or out.stride(1) != 1 or out.shape[0] != m:
+        raise capi.SamHipError("l2norm_pack: x / out must be row-major with the same number of rows")
+    capi.call("sam_l2norm_pack_bf16", capi.ptr(x), x.stride(0), m, d, int(bool(normalize)), float(eps), capi.ptr(out), out.stride(0), int(col0), int(zero_upto),
+              capi.stream_handle())
+    return out
+
+
+def embed_sum_fwd(pos, tt, rows, seq, table=None, ids=None, type_ids=None):
+    """fp32 [rows, D] = table[ids] (bf16, optional) + pos[r % seq] + tt[type_ids[r]] (type 0 when type_ids is None)"""
+    d = pos.shape[1]
+    out = torch.empty((rows, d), dtype=torch.float32, device=pos.device)
+    capi.call("sam_embed_sum_fwd", capi.ptr(table), table.stride(0) if table is not None else 0, capi.ptr(ids), table.shape[0] if table is not None else 0,
+              capi.ptr(pos), pos.stride(0), int(seq), capi.ptr(tt), tt.stride(0), capi.ptr(type_ids), tt.shape[0], rows, d, capi.ptr(out), out.stride(0),
+              capi.stream_handle())
+    return out
+
+
+def embed_sum_bwd(d_e, seq, d_pos, d_tt, type_ids=None, n_types=1):
+    """d_pos[s] += sum_b d_e[b*seq+s];  d_tt[t] += sum_{type==t} d_e  (d_e bf16 [R, D]; d_pos / d_tt fp32 gradient rows, accumulated)"""
+    _chk(d_e, BF16, "d_e")
+    r, d = d_e.shape
+    ws = _workspace(capi.call("sam_embed_sum_bwd_ws_bytes", int(seq), int(n_types), d), d_e.device, "embed")
+    capi.call("sam_embed_sum_bwd", capi.ptr(d_e), d_e.stride(0), r, d, int(seq), capi.ptr(type_ids), int(n_types), capi.ptr(d_pos), d_pos.stride(0),
+              capi.ptr(d_tt), d_tt.stride(0), capi.ptr(ws), capi.stream_handle())
+
+
+def gather2_add_fwd(ans, ocr, inds, n_ocr, emb=None, p_drop=0.0, seed=0, offset=0):
+    """bf16 [B*S, D] = (ind < V ? ans[ind] : ocr[b*n_ocr + ind - V]) + dropout(emb);  ans bf16 [V,D], ocr bf16 [B*n_ocr,D], inds int64 [B,S]"""
+    _chk(ans, BF16, "ans"); _chk(ocr, BF16, "ocr"); _chk(inds, torch.int64, "inds")
+    b, s = inds.shape
+    v, d = ans.shape
+    out = torch.empty((b * s, d), dtype=BF16, device=ans.device)
+    capi.call("sam_gather2_add_fwd", capi.ptr(ans), ans.stride(0), v, capi.ptr(ocr), ocr.stride(0), int(n_ocr), capi.ptr(inds), b, s, d, capi.ptr(emb),
+              emb.stride(0) if emb is not None else 0, float(p_drop), int(seed), int(offset), capi.ptr(out), out.stride(0), capi.stream_handle())
+    return out
+
+
+def gather2_add_bwd(dy, inds, v, n_ocr, want_emb=True, p_drop=0.0, seed=0, offset=0):
+    """-> (d_ans fp32 [V,D], d_ocr fp32 [B*n_ocr,D], d_emb bf16 [B*S,D] | None)"""
+    _chk(dy, BF16, "dy")
+    b, s = inds.shape
+    d = dy.shape[1]
+    d_ans = torch.zeros((v, d), dtype=torch.float32, device=dy.device)
+    d_ocr = torch.zeros((b * n_ocr, d), dtype=torch.float32, device=dy.device)
+    d_emb = torch.empty((b * s, d), dtype=BF16, device=dy.device) if want_emb else None
+    capi.call("sam_gather2_add_bwd", capi.ptr(dy), dy.stride(0), int(v), int(n_ocr), capi.ptr(inds), b, s, d, capi.ptr(d_ans), d_ans.stride(0), capi.ptr(d_ocr),
+              d_ocr.stride(0), float(p_drop), int(seed), int(offset), capi.ptr(d_emb), d_emb.stride(0) if want_emb else 0, capi.stream_handle())
+    return d_ans, d_ocr, d_emb
+
+
 # ----------------------------------------------------------------------------- loss / pointer net / optimizer
 def bce_loss(fixed, ocr, targets, loss_mask, grad_scale=1.0):
     """fixed f32 [R,V], ocr f32 [R,No], targets f32 [R,V+No], loss_mask f32 [R] -> (loss f32 [1], d_fixed bf16 [R,V], d_ocr f32 [R,No])"""

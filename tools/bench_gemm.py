@@ -20,6 +20,10 @@ for (N, K) in [(768, 768), (2304, 768), (3072, 768), (768, 3072)]:
     for ft in (128, 160, 192, 0):
         us = t(lambda: ops.gemm(x, w, force_tile=ft)); rows.append(("fwd  M=%d N=%d K=%d tile=%d" % (R, N, K, ft), us, 2.0 * R * N * K))
         us = t(lambda: ops.gemm(dy, w, b_kcontig=False, force_tile=ft)); rows.append(("dgrad M=%d N=%d K=%d tile=%d" % (R, K, N, ft), us, 2.0 * R * N * K))
+    # library calibration (hipBLASLt / rocBLAS through torch.matmul) on the same three products -- not part of the product path
+    us = t(lambda: torch.matmul(x, w.t())); rows.append(("LIB fwd  M=%d N=%d K=%d" % (R, N, K), us, 2.0 * R * N * K))
+    us = t(lambda: torch.matmul(dy, w)); rows.append(("LIB dgrad M=%d N=%d K=%d" % (R, K, N), us, 2.0 * R * N * K))
+    us = t(lambda: torch.matmul(dy.t(), x)); rows.append(("LIB wgrad out=%dx%d rows=%d" % (N, K, R), us, 2.0 * R * N * K))
     for sk in (-1, 3, 4, 5, 6, 8, 12, 14):
         try:
             us = t(lambda: ops.gemm(dy, x, a_kcontig=False, b_kcontig=False, out=out, accumulate=True, split_k=sk))
