@@ -33,40 +33,57 @@ __device__ __forceinline__ void st4_bf16(void* p, int64_t idx, const float* v) {
 }
 
 // ------------------------------------------------------------------------------------------ layernorm
+constexpr int LN_FWD_ROWS = 1;   // rows per wave (2 measured slower: 16.0 vs 14.7 us at 11648 x 768, HBM-cold)
 template <typename InT, int NCH>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D,
                                                      void* y, int64_t ldy, float* mean_out, float* rstd_out) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int lane = threadIdx.x & 63, row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * LN_FWD_ROWS;
+  if (row0 >= M) return;
   const int nchunk = D >> 2;
-  float v[NCH][4];
-  float s = 0.f;
+  float v[LN_FWD_ROWS][NCH][4];
 #pragma unroll
-  for (int j = 0; j < NCH; ++j) {
-    const int c = lane + 64 * j;
-    v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
-    if (c < nchunk) Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, v[j]);
-    s += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  for (int i = 0; i < LN_FWD_ROWS; ++i) {   // unconditional loads at a clamped (row, chunk): a predicated load becomes a branch + vmcnt(0)
+    const int row = min(row0 + i, M - 1);
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * min(lane + 64 * j, nchunk - 1), v[i][j]);
   }
-  const float mean = wave_sum(s) / D;
-  float q = 0.f;
-#pragma unroll
-  for (int j = 0; j < NCH; ++j)
-    if (lane + 64 * j < nchunk)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { const float d = v[j][e] - mean; q += d * d; }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+  float g4[NCH][4], b4[NCH][4];
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
-    const int c = lane + 64 * j;
-    if (c < nchunk) {
-      const float4 g4 = *reinterpret_cast<const float4*>(gamma + 4 * c), b4 = *reinterpret_cast<const float4*>(beta + 4 * c);
-      const float o[4] = {g4.x * ((v[j][0] - mean) * rstd) + b4.x, g4.y * ((v[j][1] - mean) * rstd) + b4.y,
-                          g4.z * ((v[j][2] - mean) * rstd) + b4.z, g4.w * ((v[j][3] - mean) * rstd) + b4.w};
-      st4_bf16(y, (int64_t)row * ldy + 4 * c, o);
+    const int c = min(lane + 64 * j, nchunk - 1);
+    Ld4<float>::ld(gamma, 4 * c, g4[j]);
+    Ld4<float>::ld(beta, 4 * c, b4[j]);
+  }
+#pragma unroll
+  for (int i = 0; i < LN_FWD_ROWS; ++i) {
+    const int row = row0 + i;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      if (lane + 64 * j >= nchunk) v[i][j][0] = v[i][j][1] = v[i][j][2] = v[i][j][3] = 0.f;
+      s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
     }
+    const float mean = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      if (lane + 64 * j < nchunk)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    if (row >= M) continue;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nchunk) {
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = g4[j][e] * ((v[i][j][e] - mean) * rstd) + b4[j][e];
+        st4_bf16(y, (int64_t)row * ldy + 4 * c, o);
+      }
+    }
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
   }
-  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
 // ws layout: [LN_PARTIAL_BLOCKS][3][D]  (dgamma, dbeta, dbias partials)
@@ -87,8 +104,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
 #pragma unroll
   for (int j = 0; j < NCH; ++j) {
     const int c = lane + 64 * j;
-    gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
-    if (c < nchunk) Ld4<float>::ld(gamma, 4 * c, gm[j]);
+    Ld4<float>::ld(gamma, 4 * min(c, nchunk - 1), gm[j]);
+    if (c >= nchunk) gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
   }
   // LN_ROWS rows per wave in flight: all their loads are issued before the first reduction, so one wave keeps LN_ROWS x 3 KB
   // outstanding (8 waves/CU x 9 KB covers the HBM latency-bandwidth product; one row at a time reached 1.8 TB/s)
@@ -98,19 +115,17 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
     float xv[LN_ROWS][NCH][4], dv[LN_ROWS][NCH][4], mu[LN_ROWS];
 #pragma unroll
     for (int i = 0; i < LN_ROWS; ++i) {
-      const int row = row0 + i * rstride;
-      const bool live = row < M;
-      mu[i] = live ? mean[row] : 0.f;
+      // every load is unconditional, at a clamped (row, chunk): a predicated load compiles to a branch + s_waitcnt vmcnt(0), which left
+      // ONE load pair in flight per wave (1.8 TB/s); dead rows / chunks are zeroed after the fact
+      const bool live = row0 + i * rstride < M;
+      const int row = min(row0 + i * rstride, M - 1);
+      mu[i] = mean[row];
       rs[i] = live ? rstd[row] : 0.f;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
-        const int c = lane + 64 * j;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) xv[i][j][e] = dv[i][j][e] = 0.f;
-        if (live && c < nchunk) {
-          Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv[i][j]);
-          Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv[i][j]);
-        }
+        const int c = min(lane + 64 * j, nchunk - 1);
+        Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv[i][j]);
+        Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv[i][j]);
       }
     }
 #pragma unroll
@@ -120,6 +135,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
         const int c = lane + 64 * j;
+        if (!live || c >= nchunk)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xv[i][j][e] = dv[i][j][e] = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           xh[i][j][e] = (live && c < nchunk) ? (xv[i][j][e] - mu[i]) * rs[i] : 0.f;
@@ -182,28 +200,31 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
   }
 }
 
-// out[c] (+)= sum_r ws[r*stride + c]   (deterministic order).  64 columns x 4 row lanes per block; grid.y selects one of up to three
-// (column offset, output) pairs so the LN backward finishes dgamma/dbeta/dbias in one launch.
+// out[c] (+)= sum_r ws[r*stride + c]   (deterministic order).  64 columns x 16 row lanes per block (every thread keeps 8 independent,
+// unconditional loads in flight: the kernel is pure latency); grid.y selects one of up to three (column offset, output) pairs so the
+// LN backward finishes dgamma/dbeta/dbias in one launch.
 struct FinalizeOuts { float* out[3]; int64_t col0[3]; };
-__global__ __launch_bounds__(256) void partial_finalize_kernel(const float* ws, int nrows, int64_t stride, int ncols, FinalizeOuts o, int accumulate) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
-  const float* base = ws + o.col0[blockIdx.y];
+constexpr int FIN_RL = 16;
+__global__ __launch_bounds__(64 * FIN_RL) void partial_finalize_kernel(const float* ws, int nrows, int64_t stride, int ncols, FinalizeOuts o, int accumulate) {
+  __shared__ float red[FIN_RL][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = min((int)blockIdx.x * 64 + cx, ncols - 1);
+  const float* base = ws + o.col0[blockIdx.y] + c;
   float s = 0.f;
-  if (c < ncols) {
-    int r = ry;
-    for (; r + 28 < nrows; r += 32) {
-      float t[8];
+  for (int r = ry; r < nrows; r += FIN_RL * 8) {
+    float t[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = base[(int64_t)(r + 4 * u) * stride + c];
-      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
-    }
-    for (; r < nrows; r += 4) s += base[(int64_t)r * stride + c];
+    for (int u = 0; u < 8; ++u) t[u] = base[(int64_t)min(r + FIN_RL * u, nrows - 1) * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (r + FIN_RL * u >= nrows) t[u] = 0.f;
+    s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
   }
   red[ry][cx] = s;
   __syncthreads();
-  if (ry == 0 && c < ncols) {
-    const float tot = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (ry == 0 && (int)blockIdx.x * 64 + cx < ncols) {
+    float tot = 0.f;
+#pragma unroll
+    for (int u = 0; u < FIN_RL; ++u) tot += red[u][cx];
     float* out = o.out[blockIdx.y];
     out[c] = accumulate ? out[c] + tot : tot;
   }
@@ -413,7 +434,7 @@ extern "C" int sam_layernorm_fwd(const void* x, int x_is_f32, int64_t ldx, const
   SAM_REQUIRE(x && gamma && beta && y && mean && rstd, "sam_layernorm_fwd: null pointer");
   SAM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && D <= 2048 && ldx % 4 == 0 && ldy % 4 == 0, "sam_layernorm_fwd: need D %% 4 == 0, D <= 2048 (M=%d D=%d)", M, D);
   const int nch = (D / 4 + 63) / 64;
-  const dim3 grid((M + 3) / 4);
+  const dim3 grid((M + 4 * LN_FWD_ROWS - 1) / (4 * LN_FWD_ROWS));
   int rc = x_is_f32 ? ln_fwd_dispatch<float>(nch, grid, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, D, y, ldy, mean, rstd)
                     : ln_fwd_dispatch<bf16_t>(nch, grid, (hipStream_t)stream, x, ldx, gamma, beta, eps, M, D, y, ldy, mean, rstd);
   if (rc) return rc;
@@ -442,7 +463,7 @@ extern "C" int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int
   SAM_LAUNCH_CHECK();
   // dbias of the dense in front of this LN = column sums of the (dropout-masked) dx
   FinalizeOuts fo = {{dgamma, dbeta, dbias}, {0, D, 2 * (int64_t)D}};
-  partial_finalize_kernel<<<dim3((D + 63) / 64, dbias ? 3 : 2), dim3(256), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, fo, accumulate);
+  partial_finalize_kernel<<<dim3((D + 63) / 64, dbias ? 3 : 2), dim3(64 * FIN_RL), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, fo, accumulate);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -455,7 +476,7 @@ extern "C" int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* 
   hipStream_t st = (hipStream_t)stream;
   colsum_partial_kernel<<<dim3((N / 4 + 255) / 256, COLSUM_CHUNKS), dim3(256), 0, st>>>((const bf16_t*)x, ldx, M, N, ws);
   FinalizeOuts fo = {{out, nullptr, nullptr}, {0, 0, 0}};
-  partial_finalize_kernel<<<dim3((N + 63) / 64, 1), dim3(256), 0, st>>>(ws, COLSUM_CHUNKS, N, N, fo, accumulate);
+  partial_finalize_kernel<<<dim3((N + 63) / 64, 1), dim3(64 * FIN_RL), 0, st>>>(ws, COLSUM_CHUNKS, N, N, fo, accumulate);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
