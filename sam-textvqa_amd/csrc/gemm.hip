@@ -10,6 +10,7 @@
 // template without any transpose pass through HBM.
 // The MFMA is issued "transposed" (rows = n, cols = m) so each lane ends up with 4 CONSECUTIVE n of one
 // output row: bias/residual/aux are 8- or 16-byte vector accesses and stores are 8 B (bf16) / 16 B (fp32).
+#include <type_traits>
 #include "common.h"
 #include "sam_hip.h"
 #include <stdlib.h>
@@ -244,29 +245,72 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
   int64_t ldc = p.ldc;
   int accumulate = p.accumulate;
   if (p.split_k > 1) { Cout = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; accumulate = 0; }
-  // epilogue: lane owns rows m = m0 + wm*(BM/WM) + tm*16 + i, columns n = n0 + wn*(BN/WN) + tn*16 + 4g .. +3
+  // epilogue: lane owns rows m = m0 + wm*(BM/WM) + tm*16 + i, columns n = n0 + wn*(BN/WN) + tn*16 + 4g .. +3.
+  // Every global operand of the epilogue (bias, residual, GELU pre-activation) is fetched up front for ALL fragments, unconditionally
+  // at clamped addresses: a load under a per-lane predicate compiles to branch + s_waitcnt vmcnt(0), i.e. TM*TN dependent HBM round
+  // trips per wave (24 for the 192x128 tile) instead of one.
+  // Interior tiles (wave-uniform test) run the epilogue with no per-lane predicate at all: under a predicate the compiler sinks each
+  // fragment's arithmetic into the guarded block and opens it with s_waitcnt vmcnt(0), which also waits for the PREVIOUS fragment's
+  // store -- TM*TN serialized store round trips.  Edge tiles take the same code with clamped loads and guarded stores.
+  const int n_last = max(p.N - 4, 0), m_last = p.M - 1;
+  auto epilogue = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  float4 b4[TN];
+  uint2 pre[HAS_PRE ? TM : 1][HAS_PRE ? TN : 1];
+  if (HAS_BIAS) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+      b4[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) b4[tn] = *reinterpret_cast<const float4*>(p.bias + (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
+    }
+  }
+  if (HAS_PRE) {
+    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
+    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) pre[tm][tn] = make_uint2(0u, 0u);
+    if (src)
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+          pre[tm][tn] = *reinterpret_cast<const uint2*>(src + (int64_t)(FULL ? m0 + wm * (BM / WM) + tm * 16 + i : min(m0 + wm * (BM / WM) + tm * 16 + i, m_last)) * lds_ +
+                                                        (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
+  }
+  constexpr bool F32_OUT = sizeof(OutT) == 4 && TM * TN <= 16;   // (the 256-wide test tiles keep the per-fragment read-modify-write: no registers left)
+  float4 cpre[F32_OUT ? TM : 1][F32_OUT ? TN : 1];    // accumulate=1 (wgrad into the gradient buffer): the old C values, same batching
+  if (F32_OUT && accumulate) {
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn)
+        cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0] = *reinterpret_cast<const float4*>(
+            reinterpret_cast<const float*>(Cout) + (int64_t)(FULL ? m0 + wm * (BM / WM) + tm * 16 + i : min(m0 + wm * (BM / WM) + tm * 16 + i, m_last)) * ldc + (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
+  }
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int m = m0 + wm * (BM / WM) + tm * 16 + i;
-    if (m >= p.M) continue;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
       const int n = n0 + wn * (BN / WN) + tn * 16 + 4 * g;
-      if (n >= p.N) continue;
       float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
-      if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES) {
-        if (p.bias) {
-          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-          v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-        }
+      if (F32_OUT && accumulate) {
+        const float4 c = cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0];
+        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
       }
+      if (HAS_BIAS) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
       if (EPI == SAM_EPI_BIAS_GELU) {
-        *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+        if (FULL || (m < p.M && n < p.N))
+          *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
       if (EPI == SAM_EPI_DGELU) {
-        const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
+        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];
         v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
         v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
       }
@@ -279,14 +323,15 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
           v[2] = (hi & 0xffffu) >= p.thr16 ? v[2] * p.inv_keep : 0.f;
           v[3] = (hi >> 16) >= p.thr16 ? v[3] * p.inv_keep : 0.f;
         }
-        if (p.residual) {
-          const uint2 x = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldr + n);
-          v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
-        }
+        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];   // zeros when there is no residual
+        v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
       }
-      Store4<OutT>::st(Cout, (int64_t)m * ldc + n, v, accumulate);
+      if (FULL || (m < p.M && n < p.N)) Store4<OutT>::st(Cout, (int64_t)m * ldc + n, v, F32_OUT ? 0 : accumulate);
     }
   }
+  };
+  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
+  else epilogue(std::false_type{});
 }
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
