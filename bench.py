@@ -90,6 +90,20 @@ def pmc_traffic(kernel_key):
     return round(sum(v["hbm_bytes"] * v["launches_profiled"] for v in sel) / calls)
 
 
+def pmc_mfma_util(kernel_key):
+    """MFMA-pipe utilisation of `kernel_key` from the committed PMC summary (profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES over
+    the kernel's SIMD-cycles, a separate rocprofv3 --pmc pass of this same command); None when no summary is committed"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_mfma.json")))
+    if not files:
+        return None
+    kern = json.load(open(files[-1]))["kernels"]
+    if kernel_key == "gemm_grouped_wgrad":
+        sel = [v for k, v in kern.items() if k.startswith("gemm_group_kernel")]
+        return sel[0]["mfma_util"] if sel else None
+    return None
+
+
 def roofline_from(agg):
     total_ms = sum(a["ms"] for a in agg.values())
     table = []
@@ -106,7 +120,8 @@ def roofline_from(agg):
     if top["kernel"].startswith("gemm"):
         ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
         roof = dict(kernel=top["kernel"], bound="mfma", achieved=round(ach, 1), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_BF16_TFLOPS, 4),
-                    traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], flops_per_launch=a["flops"] / a["calls"])
+                    traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], flops_per_launch=a["flops"] / a["calls"],
+                    mfma_util_pmc=pmc_mfma_util(top["kernel"]))
     else:
         ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
         roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),

@@ -56,6 +56,23 @@ def main():
                               "expected_write": round(wb * n), "measured_write": out["kernels"][k]["hbm_write_bytes"]}
         out["calibration"] = cal
         json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_traffic.json"), "w"), indent=1, sort_keys=True)
+    mfma_dir = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--mfma=")]
+    if mfma_dir:
+        # MFMA utilisation per kernel = busy cycles of the matrix pipes (SQ_VALU_MFMA_BUSY_CYCLES, summed over all 1024 SIMDs; one 16x16x32
+        # bf16 MFMA = 16 busy cycles, 1024 flop/cycle/SIMD = the 2.5 PFLOP/s dense peak at 2.4 GHz) over the SIMD-cycles the kernel had.
+        # rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (checked: 8 x duration x 2.4 GHz), so kernel cycles = GRBM_GUI_ACTIVE / 8.
+        cs = {c: pmc(mfma_dir[0], c) for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY")}
+        out = {"units": "per launch means; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); wait/issue fractions are of SQ_WAVE_CYCLES", "kernels": {}}
+        for k, (n, busy) in cs["SQ_VALU_MFMA_BUSY_CYCLES"].items():
+            gui = cs["GRBM_GUI_ACTIVE"][k][1] / max(cs["GRBM_GUI_ACTIVE"][k][0], 1)
+            wc = cs["SQ_WAVE_CYCLES"][k][1] / max(cs["SQ_WAVE_CYCLES"][k][0], 1)
+            e = {"launches_profiled": n, "mfma_busy_cycles": round(busy / n), "gui_active_cycles": round(gui), "mfma_util": round(busy / n / max(gui / 8 * 1024, 1), 4)}
+            if wc:
+                for c, key in (("SQ_WAIT_ANY", "wave_parked_frac"), ("SQ_WAIT_INST_ANY", "issue_stall_frac"), ("SQ_ACTIVE_INST_ANY", "issuing_frac")):
+                    e[key] = round(cs[c][k][1] / max(cs[c][k][0], 1) / wc, 3)
+            if busy or "gemm" in k or "attn" in k:
+                out["kernels"][k] = e
+        json.dump(out, open(os.path.join(ROOT, "profiles", tag + "_pmc_mfma.json"), "w"), indent=1, sort_keys=True)
     print("wrote profiles/%s_*" % tag)
 
 
