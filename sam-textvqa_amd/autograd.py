@@ -193,7 +193,11 @@ class EmbedLayerNormFn(Function):
         d_e, _ = ops.layernorm_bwd(dy, e, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
         ops.embed_sum_bwd(d_e, ctx.seq, pos_w.grad, tt_w.grad, type_ids, n_types=1 if type_ids is None else min(4, tt_w.shape[0]))
         if table_w is not None:
-            ops.embedding_bwd(d_e, ids, table_w.grad, ctx.padding_idx)
+            red = parallel.active_reducer
+            if red is not None and getattr(table_w, "_sam_sparse_reduce", False):
+                red.sparse_rows(table_w.grad, ids, d_e, ctx.padding_idx)      # data parallel: every rank's rows, table left out of the dense all-reduce
+            else:
+                ops.embedding_bwd(d_e, ids, table_w.grad, ctx.padding_idx)
         return (None,) * 10
 
 

@@ -39,7 +39,7 @@ class Trainer:
         self.max_grad_norm, self.betas, self.eps = max_grad_norm, betas, eps
         self.schedule = schedule or {}
         if reducer is None and parallel.dist.is_initialized() and (parallel.dist.get_world_size() > 1 or __import__("os").environ.get("SAM_FORCE_DIST") == "1"):
-            reducer = parallel.GradReducer(self.flat.grad)
+            reducer = parallel.GradReducer(self.flat.grad, dense_lo=self._sparse_table_end())
         self.reducer = reducer
         if reducer is not None:
             enc = getattr(getattr(model, "mmt", None), "encoder", None)
@@ -48,6 +48,15 @@ class Trainer:
                 layer._sam_region_id = rid
         self.global_step = 0
         dropout_clock.manual_seed(seed)
+
+    def _sparse_table_end(self):
+        """if the word-embedding table is the first parameter of flat storage (it is for SAM4C: text_bert comes first) its gradient is
+        exchanged row-sparsely (parallel.GradReducer.sparse_rows) and the dense all-reduce starts behind it; else 0"""
+        emb = getattr(getattr(getattr(self.model, "text_bert", None), "embeddings", None), "word_embeddings", None)
+        if emb is None or getattr(emb.weight, "_sam_index", None) != 0 or len(self.flat.layout) < 2:
+            return 0
+        emb.weight._sam_sparse_reduce = True
+        return self.flat.layout[1][0]
 
     def current_lrs(self):
         lam = lr_lambda(self.global_step, **self.schedule)     # LambdaLR: lr(step) = base * lambda(step), stepped after opt.step()

@@ -6,6 +6,7 @@ The HIP path computes in bf16 (fp32 accumulate); the goldens are fp32.  Two chec
   * vs the fp32 golden itself,
 both with a relative-to-max bound that grows with depth: every stored activation is re-rounded to bf16 (2^-9
 relative), so an L-op chain is allowed L * 2^-8; the per-kernel 1e-3 bound is enforced in the kernel tests."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -260,3 +261,51 @@ def test_cached_greedy_decode_equals_full_recompute():
         assert "_sam_decode_cache" not in bd
     assert torch.equal(outs[0][1], outs[1][1])
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][2], outs[1][2])      # same kernels, same k order: bit-identical
+
+
+_DIST_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["SAM_REPO"])
+from tests.test_model_gpu import _small_full_model
+from sam_textvqa_amd import parallel
+from sam_textvqa_amd.synthetic import clone_batch, make_batch
+from sam_textvqa_amd.trainer import Trainer
+os.environ["SAM_FORCE_DIST"] = "1"
+parallel.init_distributed()                               # 1-rank RCCL group: all-reduce / all-gather really go through RCCL
+res = []
+for dist_on in (True, False):
+    os.environ["SAM_FORCE_DIST"] = "1" if dist_on else "0"
+    model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    assert (tr.reducer is not None) == dist_on
+    if dist_on:
+        w = model.text_bert.embeddings.word_embeddings.weight
+        assert tr.reducer.dense_lo == tr.flat.layout[1][0] >= w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
+        assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    losses = [tr.step(clone_batch(batch)).item() for _ in range(4)]
+    res.append((losses, tr.flat.flat.clone()))
+torch.cuda.synchronize()
+(l1, p1), (l0, p0) = res
+print("LOSSES", l1, l0)
+assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+d = (p1 - p0).abs().max().item()
+print("MAXDIFF", d)
+assert d < 5e-3, d          # 4 Adam steps at lr 1e-3: a parameter moves <= 4e-3 in total; identical up to atomics order
+print("DIST_OK")
+"""
+
+
+def test_rccl_path_one_rank_matches_plain_trainer(tmp_path):
+    """SAM_FORCE_DIST=1: bucketed all-reduce on the side stream + the row-sparse word-embedding exchange run through RCCL in a 1-rank
+    group and must train exactly like the reducer-less path"""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _DIST_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "DIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

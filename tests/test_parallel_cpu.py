@@ -53,3 +53,49 @@ def test_single_process_reducer_is_noop():
     red = GradReducer(g, bucket_bytes=16)
     red.region_done(0); red.finish()
     assert red.world_size == 1 and torch.equal(g, torch.ones(10))
+
+
+def _sparse_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sam_textvqa_amd.parallel import GradReducer, init_distributed
+    init_distributed()
+    rows_tab, d, dense = 50, 8, 300
+    grad = torch.zeros(rows_tab * d + dense)
+    grad[rows_tab * d:] = (rank + 1.0) / world                       # dense part: pre-scaled per-rank gradients
+    red = GradReducer(grad, bucket_bytes=4 * 128, dense_lo=rows_tab * d)
+    assert red.buckets[-1][0] == rows_tab * d and all(lo >= rows_tab * d for lo, _ in red.buckets)   # the table is in no dense bucket
+    g = torch.Generator().manual_seed(100 + rank)
+    ids = torch.randint(0, rows_tab, (12,), generator=g)
+    ids[:3] = 0                                                        # padding rows: skipped
+    ids[3:5] = 7                                                       # a row both ranks (and one rank twice) touch
+    rows = torch.randn(12, d, generator=g).to(torch.bfloat16)
+    table = grad[: rows_tab * d].view(rows_tab, d)
+    red.begin_step()
+    red.sparse_rows(table, ids, rows, padding_idx=0)
+    red.finish()
+    # expectation: every rank's rows scattered, in any order
+    exp = torch.zeros(rows_tab, d)
+    for r in range(world):
+        gr = torch.Generator().manual_seed(100 + r)
+        i = torch.randint(0, rows_tab, (12,), generator=gr); i[:3] = 0; i[3:5] = 7
+        v = torch.randn(12, d, generator=gr).to(torch.bfloat16).float()
+        exp.index_add_(0, i[3:], v[3:])
+    ok = torch.allclose(table, exp, atol=1e-6) and bool((table[0] == 0).all()) and torch.allclose(grad[rows_tab * d:], torch.full((dense,), sum(range(1, world + 1)) / world))
+    q.put((rank, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sparse_table_exchange_gloo_world2():
+    """row-sparse exchange of the word-embedding gradient: all ranks end with the sum of everyone's rows, the dense buckets skip the table"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sparse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True), (1, True)]

@@ -1,0 +1,31 @@
+
+import os, sys, torch
+sys.path.insert(0, os.environ["SAM_REPO"])
+from tests.test_model_gpu import _small_full_model
+from sam_textvqa_amd import parallel
+from sam_textvqa_amd.synthetic import clone_batch, make_batch
+from sam_textvqa_amd.trainer import Trainer
+os.environ["SAM_FORCE_DIST"] = "1"
+parallel.init_distributed()                               # 1-rank RCCL group: all-reduce / all-gather really go through RCCL
+res = []
+for dist_on in (True, False):
+    os.environ["SAM_FORCE_DIST"] = "1" if dist_on else "0"
+    model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    assert (tr.reducer is not None) == dist_on
+    if dist_on:
+        w = model.text_bert.embeddings.word_embeddings.weight
+        assert tr.reducer.dense_lo == w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
+        assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    losses = [tr.step(clone_batch(batch)).item() for _ in range(4)]
+    res.append((losses, tr.flat.flat.clone()))
+torch.cuda.synchronize()
+(l1, p1), (l0, p0) = res
+print("LOSSES", l1, l0)
+assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+d = (p1 - p0).abs().max().item()
+print("MAXDIFF", d)
+assert d < 5e-3, d          # 4 Adam steps at lr 1e-3: a parameter moves <= 4e-3 in total; identical up to atomics order
+print("DIST_OK")
