@@ -378,6 +378,68 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
   }
 }
 
+// Split-K for skinny problems WITH an epilogue (TextBert at 20 tokens/sample: 240 64x64 tiles x 48 k-tiles on 256 CUs is pure
+// latency, 38 us for 6 GFLOP; the classifier dgrad: 144 tiles x 79 k-tiles, 58 us): the GEMM runs as an fp32 / no-epilogue split
+// into the workspace, this kernel sums the S partials in fixed order and applies the epilogue of the requested kind.
+template <int EPI, typename OutT>
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, int S, GemmArgs p) {
+  const int64_t mn4 = (int64_t)p.M * p.N / 4, MN = (int64_t)p.M * p.N;
+  for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < mn4; i4 += (int64_t)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(ws)[i4];
+    for (int s = 1; s < S; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(ws + (int64_t)s * MN)[i4];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const int64_t e = i4 * 4;
+    const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+      if (p.bias) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+    }
+    if (EPI == SAM_EPI_BIAS_GELU) {
+      *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+    }
+    if (EPI == SAM_EPI_DGELU) {
+      const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
+      v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
+      v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
+    }
+    if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+      if (p.thr16) {   // same (row, col/8) Philox stream as the in-GEMM epilogue
+        const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+        const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
+        v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
+        v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
+        v[2] = (hi & 0xffffu) >= p.thr16 ? v[2] * p.inv_keep : 0.f;
+        v[3] = (hi >> 16) >= p.thr16 ? v[3] * p.inv_keep : 0.f;
+      }
+      if (p.residual) {
+        const uint2 x = *reinterpret_cast<const uint2*>(p.residual + (int64_t)m * p.ldr + n);
+        v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
+      }
+    }
+    Store4<OutT>::st(p.C, (int64_t)m * p.ldc + n, v, 0);
+  }
+}
+
+// split factor for the epilogue split: 64x64 tiles, fill the ~1024 resident slots (4 blocks per CU) once, >= 6 k-tiles per split
+int pick_epilogue_split(int M, int N, int K, int64_t ws_bytes) {
+  const int kt = (K + BK - 1) / BK;
+  const int64_t tiles = (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+  if (kt < 24 || tiles >= 512 || N % 4) return 1;
+  int64_t s = 1024 / tiles;
+  if (s > kt / 6) s = kt / 6;
+  if (s > 8) s = 8;
+  const int64_t per = (int64_t)M * N * (int64_t)sizeof(float);
+  if (s * per > ws_bytes) s = ws_bytes / per;
+  return s < 2 ? 1 : (int)s;
+}
+
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
 int launch_cfg(GemmArgs a, hipStream_t st) {
   constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
@@ -396,6 +458,14 @@ int launch_cfg(GemmArgs a, hipStream_t st) {
   return SAM_OK;
 }
 
+// every split s covers k-tiles [s*per, (s+1)*per), per = ceil(kt / S): shrink S until the last split is non-empty (an empty split would
+// leave its workspace slice unwritten and the reduction would add garbage)
+int no_empty_split(int kt, int s) {
+  if (s <= 1) return 1;
+  const int per = (kt + s - 1) / s;
+  return (kt + per - 1) / per;
+}
+
 // split-K factor for a given tile count: fill the `per_cu` x 256 resident block slots exactly ONCE (tiles x S just above a
 // multiple of the slot count costs a whole extra round: measured 91 us at S=3 vs 123 us at S=4 for 144 tiles), >= 4 k-tiles per split
 int pick_split(int requested, int tiles, int kt, int per_cu, int64_t per_split_bytes, int64_t ws_bytes) {
@@ -407,7 +477,7 @@ int pick_split(int requested, int tiles, int kt, int per_cu, int64_t per_split_b
   }
   if (s > kt) s = kt;
   if (per_split_bytes > 0 && (int64_t)s * per_split_bytes > ws_bytes) s = (int)(ws_bytes / per_split_bytes);
-  return s < 1 ? 1 : s;
+  return no_empty_split(kt, s < 1 ? 1 : s);
 }
 
 // Block-tile choice.  Two 128x128 blocks fit a CU (LDS), i.e. 512 concurrent tiles; a grid of 546 tiles (M=11648, N=768, the
@@ -530,7 +600,52 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.defer_reduce = d->defer_reduce;
   a.split_used = const_cast<int32_t*>(&d->split_k_used);
   SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
+  if (d->epilogue == SAM_EPI_BIAS_GELU) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
+  if (d->epilogue == SAM_EPI_DGELU) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU needs aux_in");
+  if (d->epilogue == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
   int want_split = (d->split_k == 1) ? 0 : d->split_k;
+  hipStream_t st = (hipStream_t)stream;
+  if (want_split != 0 && !(d->c_is_f32 && d->epilogue == SAM_EPI_NONE && d->accumulate)) {
+    // epilogue split (see splitk_epilogue_kernel): split_k = -1 lets the library decide, and it may decide not to
+    SAM_REQUIRE(!d->accumulate && !d->bias_grad, "sam_gemm_bf16: split_k with an epilogue cannot accumulate / reduce a bias gradient");
+    SAM_REQUIRE(d->ws && ((uintptr_t)d->ws % 16 == 0), "sam_gemm_bf16: split_k needs a 16-byte aligned workspace");
+    int S = want_split < 0 ? pick_epilogue_split(d->M, d->N, d->K, d->ws_bytes) : want_split;
+    if (S > (d->K + BK - 1) / BK) S = (d->K + BK - 1) / BK;
+    S = no_empty_split((d->K + BK - 1) / BK, S);
+    SAM_REQUIRE((int64_t)S * d->M * d->N * (int64_t)sizeof(float) <= d->ws_bytes || S <= 1, "sam_gemm_bf16: workspace too small for split_k=%d", S);
+    if (S > 1) {
+      GemmArgs g = a;
+      g.bias = nullptr; g.residual = nullptr; g.aux_out = nullptr; g.aux_in = nullptr; g.thr16 = 0; g.accumulate = 0;
+      g.tiles_m = (d->M + 63) / 64; g.tiles_n = (d->N + 63) / 64; g.split_k = S; g.group_m = 1; g.defer_reduce = 1; g.bias_grad = nullptr;
+      const int lay2 = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
+      int rc = lay2 == 3 ? launch_cfg<64, 64, 2, 2, true, true, SAM_EPI_NONE, float>(g, st)
+             : lay2 == 2 ? launch_cfg<64, 64, 2, 2, true, false, SAM_EPI_NONE, float>(g, st)
+             : lay2 == 0 ? launch_cfg<64, 64, 2, 2, false, false, SAM_EPI_NONE, float>(g, st) : SAM_ERR_UNSUPPORTED;
+      if (rc) { if (rc == SAM_ERR_UNSUPPORTED) sam_set_error("sam_gemm_bf16: no split kernel for layout (0,1)"); return rc; }
+      const int64_t mn4 = (int64_t)d->M * d->N / 4;
+      const dim3 grid((unsigned)min((int64_t)2048, (mn4 + 255) / 256));
+      const int e2 = d->epilogue;
+#define SAM_SPLIT_EPI(E, T) splitk_epilogue_kernel<E, T><<<grid, dim3(256), 0, st>>>(d->ws, S, a)
+      if (d->c_is_f32) {
+        if (e2 == SAM_EPI_NONE) SAM_SPLIT_EPI(SAM_EPI_NONE, float);
+        else if (e2 == SAM_EPI_BIAS) SAM_SPLIT_EPI(SAM_EPI_BIAS, float);
+        else { sam_set_error("sam_gemm_bf16: fp32 output supports epilogues NONE / BIAS only"); return SAM_ERR_UNSUPPORTED; }
+      } else {
+        if (e2 == SAM_EPI_NONE) SAM_SPLIT_EPI(SAM_EPI_NONE, bf16_t);
+        else if (e2 == SAM_EPI_BIAS) SAM_SPLIT_EPI(SAM_EPI_BIAS, bf16_t);
+        else if (e2 == SAM_EPI_BIAS_GELU) SAM_SPLIT_EPI(SAM_EPI_BIAS_GELU, bf16_t);
+        else if (e2 == SAM_EPI_DGELU) SAM_SPLIT_EPI(SAM_EPI_DGELU, bf16_t);
+        else if (e2 == SAM_EPI_BIAS_DROPOUT_RES) SAM_SPLIT_EPI(SAM_EPI_BIAS_DROPOUT_RES, bf16_t);
+        else { sam_set_error("sam_gemm_bf16: unknown epilogue %d", e2); return SAM_ERR_UNSUPPORTED; }
+      }
+#undef SAM_SPLIT_EPI
+      SAM_LAUNCH_CHECK();
+      *const_cast<int32_t*>(&d->split_k_used) = S;
+      return SAM_OK;
+    }
+    want_split = 0;      // not worth splitting: the plain path below
+    *const_cast<int32_t*>(&d->split_k_used) = 1;
+  }
   if (want_split != 0) {
     SAM_REQUIRE(d->c_is_f32 && d->epilogue == SAM_EPI_NONE && d->accumulate, "sam_gemm_bf16: split_k needs an fp32 C with accumulate=1 and no epilogue");
     SAM_REQUIRE(d->ws && ((uintptr_t)d->ws % 16 == 0), "sam_gemm_bf16: split_k needs a 16-byte aligned workspace");
@@ -541,12 +656,8 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
   SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192 or 256");
-  hipStream_t st = (hipStream_t)stream;
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
-  if (e == SAM_EPI_BIAS_GELU) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
-  if (e == SAM_EPI_DGELU) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU needs aux_in");
-  if (e == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T
     if (d->c_is_f32) {
       if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, float>(a, st, want_split, wsb, ft);

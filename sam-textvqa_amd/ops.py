@@ -143,14 +143,18 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     aux = aux_out if aux_out is not None else aux_in
     d.ld_aux = aux.stride(0) if aux is not None else 0
     d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
+    wgrad_split = bool(accumulate) and out.dtype == torch.float32 and epilogue == capi.EPI_NONE      # partials reduced INTO C by sam_gemm_splitk_reduce
+    if split_k == 0 and not accumulate and force_tile == 0 and M <= 4096 and K >= 1536 and M * N <= (4 << 20):
+        split_k = -1       # skinny problem with a long K (TextBert's 20 tokens/sample, classifier dgrad): let the library split K and fold
+                           # the epilogue into the partial-sum reduction (it declines when the grid already fills the chip)
     d.split_k, d.bias_grad, d.force_tile = int(split_k), _dp(bias_grad), int(force_tile)
     if split_k not in (0, 1):
-        want = split_k if split_k > 0 else 32
+        want = split_k if split_k > 0 else (32 if wgrad_split else 8)
         ws = _workspace(min(want * (M * N + M) * 4, 96 << 20), a.device, "splitk")
         d.ws, d.ws_bytes, d.defer_reduce = ws.data_ptr(), ws.numel() * 4, 1
     capi.call("sam_gemm_bf16", d, capi.stream_handle(),
               meta=dict(kernel="gemm<a_kc=%d,b_kc=%d,epi=%d,f32=%d>" % (d.a_kcontig, d.b_kcontig, d.epilogue, d.c_is_f32), flops=2.0 * M * N * K, shape=(M, N, K)))
-    if d.split_k_used > 1:   # the fixed-order reduction of the split-K partials is its own launch (and its own profile row)
+    if d.split_k_used > 1 and wgrad_split:   # the fixed-order reduction of the split-K partials is its own launch (and its own profile row)
         capi.call("sam_gemm_splitk_reduce", d.ws, d.split_k_used, M, N, out.data_ptr(), out.stride(0), d.bias_grad, capi.stream_handle(),
                   meta=dict(kernel="splitk_reduce", bytes=4.0 * M * N * (d.split_k_used + 2)))
     return out

@@ -117,8 +117,49 @@ def test_wgrad_split_k_and_fused_bias_grad(R, M, N, split):
     dw2, db2 = base.clone().cuda(), torch.full((M,), 0.5, device="cuda")
     ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw2, accumulate=True, split_k=split, bias_grad=db2)
     assert torch.equal(dw, dw2) and torch.equal(db, db2)          # fixed summation order: bit-reproducible
-    with pytest.raises(capi.SamHipError):          # split-K needs accumulate semantics
-        ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4)
+    with pytest.raises(capi.SamHipError):          # a bias gradient only comes out of the accumulate (wgrad) form of split-K
+        ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4, bias_grad=db)
+    ops.gemm(dy.cuda(), x.cuda(), a_kcontig=False, b_kcontig=False, out=dw, accumulate=False, split_k=4)      # store form: partials summed, C overwritten
+    assert_close_bf16(dw, ref, ulps=0, name="split-k store")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(1280, 768, 3072, -1), (768, 768, 5000, -1), (100, 72, 1600, 3), (1280, 3072, 768, -1), (64, 8, 4096, 8)])
+def test_split_k_with_epilogue_matches_unsplit(M, N, K, split):
+    """skinny problems (TextBert's 20 tokens/sample, classifier dgrad) split K and fold the epilogue into the partial-sum reduction:
+    every epilogue, forward and dgrad layouts, against the un-split kernel (force_tile=64 disables the automatic split) and torch"""
+    ops, capi = _mods()
+    x, w, dy = rnd((M, K), 31), rnd((N, K), 32, 0.05), rnd((M, K), 33)
+    wT = rnd((K, N), 34, 0.05)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(35)).cuda()
+    res, pre = rnd((M, N), 36).cuda(), rnd((M, N), 37).cuda()
+    xg, wg, dyg, wTg = x.cuda(), w.cuda(), dy.cuda(), wT.cuda()
+    ref = x.float() @ w.float().t()
+    got = ops.gemm(xg, wg, split_k=split)
+    assert_close_bf16(got, ref, name="split fwd none")
+    got = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bias, out_dtype=torch.float32, split_k=split)
+    assert_close_bf16(got, ref + bias.cpu(), ulps=0, name="split fwd bias f32")
+    aux = torch.empty((M, N), dtype=torch.bfloat16, device="cuda")
+    got = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_GELU, bias=bias, aux_out=aux, split_k=split)
+    assert_close_bf16(aux, ref + bias.cpu(), name="split gelu pre-activation")
+    assert_close_bf16(got, gelu(ref + bias.cpu()), name="split gelu")
+    # dgrad layout: dy[M,K] . W[K,N]
+    refd = dy.float() @ wT.float()
+    got = ops.gemm(dyg, wTg, b_kcontig=False, split_k=split)
+    assert_close_bf16(got, refd, name="split dgrad none")
+    got = ops.gemm(dyg, wTg, b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre, split_k=split)
+    one = ops.gemm(dyg, wTg, b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre, force_tile=64)
+    assert_close_bf16(got, one.float(), ulps=2, name="split dgelu vs unsplit")
+    for p in (0.0, 0.1):
+        got = ops.gemm(dyg, wTg, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bias, residual=res, p_drop=p, seed=5, offset=9, split_k=split)
+        one = ops.gemm(dyg, wTg, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bias, residual=res, p_drop=p, seed=5, offset=9, force_tile=64)
+        assert_close_bf16(got, one.float(), ulps=2, name="split dropout+res vs unsplit (same Philox stream) p=%g" % p)
+    if p and M * N > 50000:
+        dropped = ((got.float() - res.float()).abs() < 1e-6).float().mean().item()
+        assert abs(dropped - 0.1) < 0.02, dropped
+    # bit-reproducible
+    a1 = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bias, split_k=split)
+    a2 = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bias, split_k=split)
+    assert torch.equal(a1, a2)
 
 
 @pytest.mark.parametrize("tile", [64, 128, 160, 192, 256])
