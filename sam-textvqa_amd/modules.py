@@ -491,6 +491,10 @@ class MMT(_HipModule):
     def forward(self, batch_dict, fixed_ans_emb):
         self._ready()
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, batch_dict["ocr_mmt_in"], batch_dict["train_prev_inds"])
+        ev = batch_dict.pop("_sam_tb_event", None)
+        if ev is not None:                                # TextBert ran on a side stream (SAM4C.forward): join it here, as late as possible
+            torch.cuda.current_stream().wait_event(ev)
+            batch_dict["text_bert_emb"].record_stream(torch.cuda.current_stream())
         x = torch.cat([batch_dict["text_bert_emb"].to(BF16), batch_dict["obj_mmt_in"].to(BF16), batch_dict["ocr_mmt_in"].to(BF16),
                        dec_emb.to(BF16)], dim=1)
         n_txt = batch_dict["question_mask"].size(-1)
@@ -594,6 +598,8 @@ class SAM4C(_HipModule):
         n_out = num_answers if num_answers is not None else len(registry.answer_vocab)
         self.bos_idx = bos_idx if bos_idx is not None else registry.BOS_IDX
         self.classifier = nn.Linear(h, n_out)
+        self.overlap_text_bert = __import__("os").environ.get("SAM_NO_TB_OVERLAP") != "1"
+        self._side_stream = None
         self.decode_cache = True      # eval-mode greedy loop re-runs only the decoder rows (set False for the reference's 12 full passes)
 
     def _forward_obj_encoding(self, bd):
@@ -611,11 +617,16 @@ class SAM4C(_HipModule):
              + layer_norm(linear(bd["pad_ocr_bboxes"][:, :, :-1].to(BF16), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
         bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)
 
+    def _forward_text_bert(self, bd):
+        t = self.text_bert(bd)
+        bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+
     def _forward_mmt(self, bd):
         cache = bd.get("_sam_decode_cache")
-        if cache is None or "text_bert_emb" not in cache:
-            t = self.text_bert(bd)
-            bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+        if cache is not None and "text_bert_emb" in cache:
+            bd["text_bert_emb"] = cache["text_bert_emb"]
+        elif not bd.pop("_sam_tb_ready", False):       # (already computed on the side stream by forward())
+            self._forward_text_bert(bd)
             if cache is not None:
                 cache["text_bert_emb"] = bd["text_bert_emb"]      # question encoding does not depend on the decoding step
         bd.update(self.mmt(bd, fixed_ans_emb=self.classifier.weight))
@@ -630,8 +641,25 @@ class SAM4C(_HipModule):
         if use_beam_search:
             raise NotImplementedError("beam search is disabled upstream (train.py:222-225) and out of scope")
         self._ready()
-        self._forward_obj_encoding(batch_dict)
-        self._forward_ocr_encoding(batch_dict)
+        if self.training and self.overlap_text_bert:
+            # TextBert (20 tokens/sample: 240-block grids, latency-bound) runs on a side stream underneath the object / OCR encoders; autograd
+            # replays each node's backward on its forward stream, so its backward overlaps theirs too
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._forward_text_bert(batch_dict)
+            batch_dict["_sam_tb_ready"] = True
+            ev = torch.cuda.Event()
+            ev.record(side)
+            batch_dict["_sam_tb_event"] = ev             # joined by MMT.forward right before it concatenates the four token groups
+            self._forward_obj_encoding(batch_dict)
+            self._forward_ocr_encoding(batch_dict)
+        else:
+            self._forward_obj_encoding(batch_dict)
+            self._forward_ocr_encoding(batch_dict)
         if self.training:
             self._forward_mmt(batch_dict)
             self._forward_output(batch_dict)
