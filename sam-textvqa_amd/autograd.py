@@ -104,7 +104,9 @@ class LinearFn(Function):
         wv, gv, _, dbv, n_pad, k_pad = _padded_views(weight, bias)
         n, k = weight.shape
         dy2 = dy.reshape(-1, n)
-        if n_pad != n or dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+        if n_pad == n and dy2.dtype != BF16 and dy2.is_contiguous():
+            dy2 = dy2.to(BF16)                                   # fp32 scores (classifier): one cast, no padding needed
+        elif n_pad != n or dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
             dp = torch.zeros((dy2.shape[0], n_pad), dtype=BF16, device=dy.device)
             dp[:, :n] = dy2
             dy2 = dp
@@ -327,15 +329,17 @@ class BceLossFn(Function):
     """M4CDecodingBCEWithMaskLoss (sam/task_utils.py:19-30) on the two score blocks; gradient computed in the forward pass"""
 
     @staticmethod
-    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale):
+    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale, unit_grad=False):
         r = fixed.shape[0] * fixed.shape[1]
         f2, o2 = fixed.reshape(r, -1), ocr.reshape(r, -1)
         loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale)
         ctx.save_for_backward(d_fixed, d_ocr)
-        ctx.shapes = (fixed.shape, ocr.shape)
+        ctx.shapes, ctx.unit_grad = (fixed.shape, ocr.shape), unit_grad
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
-        d_fixed, d_ocr = ctx.saved_tensors   # upstream g is 1 for a scalar loss .backward(); honour it anyway
-        return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None
+        d_fixed, d_ocr = ctx.saved_tensors
+        if ctx.unit_grad:      # the caller (Trainer.step) runs loss.backward() itself: upstream gradient is exactly 1, skip three elementwise passes
+            return d_fixed.view(ctx.shapes[0]), d_ocr.view(ctx.shapes[1]), None, None, None, None
+        return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None, None

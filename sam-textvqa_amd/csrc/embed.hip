@@ -190,15 +190,35 @@ int fill_gather_args(Gather2Args& a, const void* ans, int64_t ld_ans, int V, con
   return SAM_OK;
 }
 
+// scalar twin for rows that are not 16-byte aligned / not a multiple of 4 wide (the 4 box coordinates sliced out of [.., 5] rows)
+__global__ __launch_bounds__(256) void l2norm_pack_scalar_kernel(const float* x, int64_t ldx, int M, int D, int normalize, float eps, bf16_t* out, int64_t ldo,
+                                                                 int col0, int zero_upto) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  bf16_t* orow = out + (int64_t)row * ldo;
+  float scale = 1.f;
+  if (normalize) {
+    float q = 0.f;
+    for (int c = lane; c < D; c += 64) q += xr[c] * xr[c];
+    scale = 1.0f / fmaxf(sqrtf(wave_sum(q)), eps);
+  }
+  for (int c = lane; c < D; c += 64) orow[col0 + c] = f2bf(xr[c] * scale);
+  for (int c = col0 + D + lane; c < zero_upto; c += 64) orow[c] = 0;
+}
+
 }  // namespace
 
 extern "C" int sam_l2norm_pack_bf16(const float* x, int64_t ldx, int M, int D, int normalize, float eps, void* out, int64_t ldo, int col0, int zero_upto,
                                     void* stream) {
   SAM_REQUIRE(x && out, "sam_l2norm_pack_bf16: null pointer");
-  SAM_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && col0 >= 0 && col0 % 4 == 0 && col0 + D <= ldo && zero_upto <= ldo,
-              "sam_l2norm_pack_bf16: need D, ldx, ldo, col0 multiples of 4 and col0 + D <= ldo (M=%d D=%d col0=%d ldo=%ld)", M, D, col0, (long)ldo);
-  SAM_REQUIRE(((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0, "sam_l2norm_pack_bf16: x must be 16-byte and out 8-byte aligned");
-  l2norm_pack_kernel<<<dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
+  SAM_REQUIRE(M > 0 && D > 0 && col0 >= 0 && col0 + D <= ldo && zero_upto <= ldo, "sam_l2norm_pack_bf16: need col0 + D <= ldo (M=%d D=%d col0=%d ldo=%ld)", M, D, col0,
+              (long)ldo);
+  const bool vec = D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && col0 % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0;
+  if (vec)
+    l2norm_pack_kernel<<<dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
+  else   // unaligned / odd-width rows (box coordinates): scalar accesses
+    l2norm_pack_scalar_kernel<<<dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -561,7 +561,8 @@ def _pack_features(parts, normalize, n_zero_cols):
     col = 0
     for i, p in enumerate(parts):
         last = i == len(parts) - 1
-        ops.l2norm_pack(p.reshape(b * n, p.shape[-1]).float().contiguous(), out, col, normalize, zero_upto=k_pad if last else 0)
+        p2 = p.float().flatten(0, 1)                      # [B*n, D] view (a column slice of wider rows stays a strided view: no copy)
+        ops.l2norm_pack(p2 if p2.stride(1) == 1 else p2.contiguous(), out, col, normalize, zero_upto=k_pad if last else 0)
         col += p.shape[-1]
     return out.view(b, n, k_pad)
 
@@ -605,7 +606,7 @@ class SAM4C(_HipModule):
     def _forward_obj_encoding(self, bd):
         feat = _pack_features([bd["pad_obj_features"]], self.normalize, 0)
         x = (layer_norm(linear(feat, self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
-             + layer_norm(linear(bd["pad_obj_bboxes"][:, :, :-1].to(BF16), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
+             + layer_norm(linear(_pack_features([bd["pad_obj_bboxes"][:, :, :-1]], False, 0), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
         bd["obj_mmt_in"] = F.dropout(x, self.obj_drop_p, self.training)
 
     def _forward_ocr_encoding(self, bd):
@@ -614,7 +615,7 @@ class SAM4C(_HipModule):
         # FastText | PHOC | FRCN | 50 legacy all-zero order columns (sa_m4c.py:242), normalised and packed into the K-padded GEMM operand
         feat = _pack_features([ft, ph, fc] if self.mmt_config.use_phoc_fasttext else [fc], self.normalize, 50)
         x = (layer_norm(linear(feat, self.linear_ocr_feat_to_mmt_in), self.ocr_feat_layer_norm)
-             + layer_norm(linear(bd["pad_ocr_bboxes"][:, :, :-1].to(BF16), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
+             + layer_norm(linear(_pack_features([bd["pad_ocr_bboxes"][:, :, :-1]], False, 0), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
         bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)
 
     def _forward_text_bert(self, bd):

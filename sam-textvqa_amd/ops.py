@@ -214,8 +214,9 @@ def colsum(x, out, accumulate=True):
 def l2norm_pack(x, out, col0=0, normalize=True, zero_upto=0, eps=1e-12):
     """out[:, col0:col0+D] = bf16(F.normalize(x, dim=-1)) (normalize=False: plain cast); x fp32 [M, D]; out bf16 [M, ldo];
     columns [col0+D, zero_upto) of out are zeroed"""
-    _chk(x, torch.float32, "x")
     _chk(out, BF16, "out")
+    if not x.is_cuda or x.dtype != torch.float32 or x.dim() != 2:
+        raise capi.SamHipError("l2norm_pack: x must be a 2-D fp32 GPU tensor")
     m, d = x.shape
     if x.stride(1) != 1 or out.stride(1) != 1 or out.shape[0] != m:
         raise capi.SamHipError("l2norm_pack: x / out must be row-major with the same number of rows")

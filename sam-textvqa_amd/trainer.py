@@ -19,9 +19,11 @@ def lr_lambda(it, warmup_iters=1000, warmup_factor=0.2, lr_decay_iters=(14000, 1
     return pow(lr_decay, bisect(list(lr_decay_iters), it))
 
 
-def masked_bce_loss(batch_dict, grad_scale=1.0):
-    """M4CDecodingBCEWithMaskLoss on the score blocks SAM4C.forward left in batch_dict"""
-    return BceLossFn.apply(batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"], batch_dict["targets"], batch_dict["train_loss_mask"], grad_scale)
+def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False):
+    """M4CDecodingBCEWithMaskLoss on the score blocks SAM4C.forward left in batch_dict.  unit_grad=True: the caller promises to call
+    .backward() on the returned loss with the default gradient of 1 (the loss gradient is then handed on without being rescaled)"""
+    return BceLossFn.apply(batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"], batch_dict["targets"], batch_dict["train_loss_mask"], grad_scale,
+                           unit_grad)
 
 
 class Trainer:
@@ -72,7 +74,7 @@ class Trainer:
         parallel.active_reducer = self.reducer
         model(batch_dict)
         grad_scale = 1.0 / self.reducer.world_size if self.reducer is not None else 1.0
-        loss = masked_bce_loss(batch_dict, grad_scale)
+        loss = masked_bce_loss(batch_dict, grad_scale, unit_grad=True)
         loss.backward()
         parallel.active_reducer = None
         if self.reducer is not None:

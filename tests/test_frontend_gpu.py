@@ -40,14 +40,21 @@ def test_l2norm_pack_matches_normalize_cat(normalize):
     assert (got[5, 300:904] == 0).all()
 
 
-def test_l2norm_pack_rejects_misaligned():
+def test_l2norm_pack_unaligned_rows_and_bad_shapes():
+    """box coordinates: 4 columns sliced out of [.., 5] fp32 rows (not 16-byte aligned) go through the scalar twin; K padded 4 -> 8"""
     ops = _ops()
     from sam_textvqa_amd._capi import SamHipError
-    out = torch.empty((4, 16), dtype=BF16, device="cuda")
+    boxes = rnd((6, 50, 5), 9).cuda()
+    x = boxes[:, :, :-1].flatten(0, 1)
+    assert x.stride() == (5, 1)
+    out = torch.full((300, 8), 3.0, dtype=BF16, device="cuda")
+    ops.l2norm_pack(x, out, 0, normalize=False, zero_upto=8)
+    assert torch.equal(out[:, :4], x.to(BF16)) and (out[:, 4:] == 0).all()
+    out2 = torch.empty((300, 8), dtype=BF16, device="cuda")
+    ops.l2norm_pack(x, out2, 2, normalize=True)                           # odd column offset, normalised
+    assert_close_bf16(out2[:, 2:6], F.normalize(x, dim=-1), ulps=1, name="scalar normalize")
     with pytest.raises(SamHipError):
-        ops.l2norm_pack(torch.zeros(4, 8, device="cuda"), out, col0=2)
-    with pytest.raises(SamHipError):
-        ops.l2norm_pack(torch.zeros(4, 8, device="cuda"), out, col0=12)      # col0 + D > ldo
+        ops.l2norm_pack(torch.zeros(4, 8, device="cuda"), torch.empty((4, 16), dtype=BF16, device="cuda"), col0=12)      # col0 + D > ldo
 
 
 @pytest.mark.parametrize("with_table,with_types", [(True, False), (False, True), (True, True)])
