@@ -10,7 +10,10 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libsam_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result"]
+# -amdgpu-mfma-vgpr-form: MFMA accumulators that the VALU consumes right away (attention scores) stay in VGPRs; without it the compiler
+# put them in AGPRs and copied every value across with v_accvgpr_read/write (80 and 136 copies per loop trip in the two attention
+# backward kernels, none left with the flag; the GEMMs never had any)
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-unused-result", "-mllvm", "-amdgpu-mfma-vgpr-form=1"]
 
 
 def sources():
