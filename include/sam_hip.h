@@ -90,8 +90,10 @@ typedef struct sam_gemm_desc {
   const void* residual; int64_t ldr;
   void* aux_out; const void* aux_in; int64_t ld_aux;
   float p_drop; uint64_t seed, offset;
-  int32_t split_k;    /* 0/1: none; >1: split the K loop over that many workgroups per tile; -1: auto (bounded by ws_bytes).  Needs fp32 C,
-                         accumulate=1, SAM_EPI_NONE.  Partials go to `ws` and are summed in a fixed order (bit-reproducible, no atomics). */
+  int32_t split_k;    /* 0/1: none; >1: split the K loop over that many workgroups per tile; -1: auto (bounded by ws_bytes; may decide 1).
+                         Partials go to `ws` and are summed in a fixed order (bit-reproducible, no atomics).  Two forms:
+                         fp32 C + accumulate=1 + SAM_EPI_NONE (wgrad: the sum is added INTO C, bias_grad allowed), or any other
+                         epilogue / output with accumulate=0 (skinny M, long K: the epilogue is applied by the reduction pass). */
   float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] += sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad. */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
   int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height (testing, tuning) */

@@ -79,3 +79,10 @@ def test_no_oracle_import_in_product_package():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, "%s imports the oracle" % f
+
+
+def test_plain_cxx_host_program_links_against_the_c_abi(tmp_path):
+    """tests/cabi/host_smoke.cpp includes only sam_hip.h and the HIP runtime: it must compile and link (it runs in the gpu suite)"""
+    from tests.cabi_host import build_host_smoke
+    exe = build_host_smoke(tmp_path)
+    assert os.path.exists(exe)

@@ -209,3 +209,13 @@ def test_strided_views_and_errors():
         ops.gemm(rnd((16, 12), 1).cuda(), rnd((16, 12), 2).cuda())      # K % 8 != 0
     with pytest.raises(capi.SamHipError):
         ops.gemm(big, w, out=torch.empty(300, 768, dtype=torch.bfloat16, device="cuda"), accumulate=True)
+
+
+def test_c_abi_from_a_plain_cxx_host_program(tmp_path):
+    """no Python between the caller and the library: LayerNorm, bias GEMM and prefix-LM attention through include/sam_hip.h from C++,
+    each checked against a double-precision host computation inside the program"""
+    import subprocess
+    from tests.cabi_host import build_host_smoke
+    exe = build_host_smoke(tmp_path)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ABI_OK" in r.stdout, r.stdout[-3000:]
