@@ -28,25 +28,36 @@ class GradReducer:
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         # SAM_FORCE_DIST=1: run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
         self.force = dist.is_initialized() and __import__("os").environ.get("SAM_FORCE_DIST") == "1"
-        n = flat_grad.numel()
-        per = max(1, bucket_bytes // flat_grad.element_size())
-        # bucket k covers [n - (k+1)*per, n - k*per): ascending k = descending addresses = backward order
-        self.buckets = []
-        hi = n
-        while hi > self.dense_lo:
-            lo = max(self.dense_lo, hi - per)
-            self.buckets.append((lo, hi))
-            hi = lo
+        self.per_bucket = max(1, bucket_bytes // flat_grad.element_size())
+        self._build_buckets(cut=None)
+        # SAM_REDUCER_CHECK=1 (1-rank groups only, where the all-reduce is the identity): keep a copy of every bucket as it is released and
+        # verify at finish() that nothing wrote into it afterwards -- catches a premature release on a single GPU
+        self.check = __import__("os").environ.get("SAM_REDUCER_CHECK") == "1" and self.world_size == 1
         self.overlap = overlap and flat_grad.is_cuda and (self.world_size > 1 or self.force)
         self.stream = torch.cuda.Stream() if self.overlap else None
         self.regions = []
         self.begin_step()
+
+    def _build_buckets(self, cut):
+        """buckets walk the dense range [dense_lo, n) from the end (ascending index = descending addresses = backward order).  `cut`: a
+        forced boundary (the low end of the registered regions): a bucket straddling it would mix gradients that are final early (encoder
+        layers) with ones that are final last (everything below) and could only leave at finish()."""
+        n, per = self.grad.numel(), self.per_bucket
+        self.buckets = []
+        for top, bottom in ((n, cut), (cut, self.dense_lo)) if cut is not None and self.dense_lo < cut < n else ((n, self.dense_lo),):
+            hi = top
+            while hi > bottom:
+                lo = max(bottom, hi - per)
+                self.buckets.append((lo, hi))
+                hi = lo
 
     def register_regions(self, ranges):
         """[lo, hi) flat ranges of the encoder layers; returns region ids in the order given.  A bucket is released once
         every registered region at or above its low end has reported `mark_done` (layers may finish in any order)."""
         order = sorted(range(len(ranges)), key=lambda i: -ranges[i][0])
         self.regions = [ranges[i] for i in order]
+        if self.regions:
+            self._build_buckets(cut=min(lo for lo, _ in self.regions))
         ids = [0] * len(ranges)
         for pos, i in enumerate(order):
             ids[i] = pos
@@ -64,6 +75,7 @@ class GradReducer:
         self.next_bucket = 0
         self.ready_lo = self.grad.numel()      # gradients at addresses >= ready_lo are final
         self.work = []
+        self.snapshots = []
         self.done = [False] * len(self.regions)
         self.done_ptr = 0
 
@@ -72,6 +84,8 @@ class GradReducer:
         chunk = self.grad[lo:hi]
         if self.world_size == 1 and not self.force:
             return
+        if self.check:
+            self.snapshots.append((k, chunk.clone()))
         if self.overlap:
             self.stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.stream):
@@ -106,6 +120,13 @@ class GradReducer:
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.stream)
         self.work = []
+        for k, snap in self.snapshots:
+            lo, hi = self.buckets[k]
+            if not torch.equal(snap, self.grad[lo:hi]):
+                bad = (snap != self.grad[lo:hi]).nonzero()
+                raise RuntimeError("GradReducer: bucket %d [%d, %d) was released before its gradients were final (first late write at offset %d)"
+                                   % (k, lo, hi, lo + int(bad[0])))
+        self.snapshots = []
 
 
 def _scatter_rows(grad_table, ids, rows, padding_idx):

@@ -80,8 +80,13 @@ def test_reducer_bucket_plan_and_region_order():
     assert red.buckets == [(744, 1000), (488, 744), (232, 488), (0, 232)]
     ids = red.register_regions([(100, 300), (300, 600), (600, 1000)])      # layers in address order
     assert ids == [2, 1, 0]
+    # the low end of the regions becomes a bucket boundary: no bucket mixes early-final (layers) and late-final (below them) gradients
+    assert red.buckets == [(744, 1000), (488, 744), (232, 488), (100, 232), (0, 100)]
     red.mark_done(ids[0])                      # lowest layer finishing first releases nothing
     assert red.next_bucket == 0
     red.mark_done(ids[2]); assert red.next_bucket == 1          # [744,1000) complete
-    red.mark_done(ids[1]); assert red.next_bucket == 3          # everything >= 100 final -> buckets down to lo >= 100
-    red.finish(); assert red.next_bucket == 4
+    red.mark_done(ids[1]); assert red.next_bucket == 4          # everything >= 100 final -> every bucket of the region range
+    red.finish(); assert red.next_bucket == 5
+    red2 = GradReducer(torch.zeros(1000), bucket_bytes=4 * 256, dense_lo=40)     # row-sparse table in [0, 40): outside every bucket
+    red2.register_regions([(500, 1000)])
+    assert red2.buckets == [(744, 1000), (500, 744), (244, 500), (40, 244)]
