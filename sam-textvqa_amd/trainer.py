@@ -43,6 +43,8 @@ class Trainer:
         if reducer is None and parallel.dist.is_initialized() and (parallel.dist.get_world_size() > 1 or __import__("os").environ.get("SAM_FORCE_DIST") == "1"):
             reducer = parallel.GradReducer(self.flat.grad, dense_lo=self._sparse_table_end())
         self.reducer = reducer
+        if reducer is not None and parallel.dist.is_initialized() and dev.type == "cuda":
+            parallel.dist.all_reduce(self.gnorm_sq)              # (zeros) creates the RCCL communicator here, not inside the first timed step
         if reducer is not None:
             enc = getattr(getattr(model, "mmt", None), "encoder", None)
             layers = [l for name in ("normal_layers", "spatial_layers", "implicit_layers") for l in getattr(enc, name, [])] if enc is not None else []
