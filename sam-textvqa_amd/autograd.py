@@ -194,6 +194,9 @@ class EmbedLayerNormFn(Function):
             dy = dy.to(BF16).contiguous()
         d_e, _ = ops.layernorm_bwd(dy, e, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
         ops.embed_sum_bwd(d_e, ctx.seq, pos_w.grad, tt_w.grad, type_ids, n_types=1 if type_ids is None else min(4, tt_w.shape[0]))
+        rid = getattr(ln, "_sam_region_id", None)
+        if rid is not None and parallel.active_reducer is not None:
+            parallel.active_reducer.mark_done(rid)            # position / token-type / LayerNorm gradients of this embedding block are final
         if table_w is not None:
             red = parallel.active_reducer
             if red is not None and getattr(table_w, "_sam_sparse_reduce", False):
@@ -223,6 +226,78 @@ class PrevPredGatherFn(Function):
             dy = dy.to(BF16).contiguous()
         d_ans, d_ocr, d_emb = ops.gather2_add_bwd(dy, inds, v, n_ocr, ctx.needs_input_grad[2], p_drop, *ctx.seed)
         return d_ans, d_ocr, d_emb, None, None, None
+
+
+class PrevPredFn(Function):
+    """PrevPredEmbeddings.forward (sam/sa_m4c.py:900-948) as ONE autograd node:
+        LN_ans(ans_emb)[ind] or LN_ocr(ocr_emb)[b, ind - V]  +  dropout(LN_emb(pos[s] + type[ind >= V]))
+    Seven launches forward; backward writes every parameter gradient itself (ans-embedding rows go straight into the classifier weight
+    gradient: ans_emb IS the classifier weight, sa_m4c.py:273-274) and returns only d ocr_emb.  Being a single node matters for data
+    parallelism: when the gradient of `ocr_emb` arrives upstream, every gradient this module contributes is final (parallel.GradBarrierFn)."""
+
+    @staticmethod
+    def forward(ctx, anchor, ans_emb, ocr_emb, prev_inds, mod, p_drop):
+        b, s = prev_inds.shape
+        n_ocr, d = ocr_emb.shape[1], ocr_emb.shape[2]
+        ans_x = ans_emb.data if ans_emb.is_contiguous() or ans_emb.stride(1) == 1 else ans_emb.contiguous()
+        ans, m_a, r_a = ops.layernorm_fwd(ans_x, mod.ans_layer_norm.weight, mod.ans_layer_norm.bias, mod.ans_layer_norm.variance_epsilon)
+        ocr_x = ocr_emb.reshape(b * n_ocr, d)
+        if ocr_x.dtype not in (BF16, torch.float32) or ocr_x.stride(1) != 1 or ocr_x.stride(0) % 4:
+            ocr_x = ocr_x.contiguous()
+        ocr, m_o, r_o = ops.layernorm_fwd(ocr_x, mod.ocr_layer_norm.weight, mod.ocr_layer_norm.bias, mod.ocr_layer_norm.variance_epsilon)
+        inds = prev_inds.contiguous()
+        is_ocr = inds.ge(ans_emb.shape[0]).view(torch.uint8).reshape(-1)         # token type 1 for copied OCR tokens, sa_m4c.py:936
+        e = ops.embed_sum_fwd(mod.position_embeddings.weight.data, mod.token_type_embeddings.weight.data, b * s, s, type_ids=is_ocr)
+        emb, m_e, r_e = ops.layernorm_fwd(e, mod.emb_layer_norm.weight, mod.emb_layer_norm.bias, mod.emb_layer_norm.variance_epsilon)
+        ctx.seed = dropout_clock.next()
+        out = ops.gather2_add_fwd(ans, ocr, inds, n_ocr, emb, p_drop, *ctx.seed)
+        ctx.save_for_backward(ans_x, m_a, r_a, ocr_x, m_o, r_o, e, m_e, r_e, inds, is_ocr)
+        ctx.mod, ctx.ans_param, ctx.p_drop, ctx.shapes = mod, ans_emb, p_drop, (ocr_emb.shape, ocr_emb.dtype, n_ocr)
+        return out.view(b, s, d)
+
+    @staticmethod
+    def backward(ctx, dy):
+        ans_x, m_a, r_a, ocr_x, m_o, r_o, e, m_e, r_e, inds, is_ocr = ctx.saved_tensors
+        mod, ans_param = ctx.mod, ctx.ans_param
+        ocr_shape, ocr_dtype, n_ocr = ctx.shapes
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16 or not dy2.is_contiguous():
+            dy2 = dy2.to(BF16).contiguous()
+        d_ans, d_ocr, d_emb = ops.gather2_add_bwd(dy2, inds, ans_x.shape[0], n_ocr, True, ctx.p_drop, *ctx.seed)
+        ln = mod.emb_layer_norm
+        d_e, _ = ops.layernorm_bwd(d_emb, e, m_e, r_e, ln.weight, ln.weight.grad, ln.bias.grad)
+        tt = mod.token_type_embeddings.weight
+        ops.embed_sum_bwd(d_e, inds.shape[1], mod.position_embeddings.weight.grad, tt.grad, is_ocr, n_types=min(4, tt.shape[0]))
+        ln = mod.ans_layer_norm
+        dx_ans, _ = ops.layernorm_bwd(d_ans.to(BF16), ans_x, m_a, r_a, ln.weight, ln.weight.grad, ln.bias.grad)
+        ln = mod.ocr_layer_norm
+        dx_ocr, _ = ops.layernorm_bwd(d_ocr.to(BF16), ocr_x, m_o, r_o, ln.weight, ln.weight.grad, ln.bias.grad)
+        g_ans = None
+        if getattr(ans_param, "_sam_flat", None) is not None and ans_param.grad is not None:
+            ans_param.grad.add_(dx_ans)                       # prepared parameter (the classifier weight): accumulate here, not through autograd
+        elif ctx.needs_input_grad[1]:
+            g_ans = dx_ans.to(ans_param.dtype)
+        g_ocr = dx_ocr.view(ocr_shape).to(ocr_dtype) if ctx.needs_input_grad[2] else None
+        return None, g_ans, g_ocr, None, None, None
+
+
+class GradBarrierFn(Function):
+    """identity; its backward runs when the COMPLETE gradient of `x` has arrived, i.e. after every consumer of x has run its backward
+    (autograd's dependency counting), and then reports `name` to the active gradient reducer.  SAM4C puts one on each of the three
+    encoder outputs that feed the MMT (question, objects, OCR): once all three have fired, everything downstream of them -- the MMT
+    layers, PrevPredEmbeddings, the classifier and the pointer network -- has finished its backward, so those gradients are final."""
+
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        red = parallel.active_reducer
+        if red is not None:
+            red.barrier_hit(ctx.name)
+        return g, None
 
 
 # ------------------------------------------------------------------------------------------------ encoder layer

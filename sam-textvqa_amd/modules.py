@@ -15,7 +15,7 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, PrevPredGatherFn, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, PrevPredFn, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -469,13 +469,8 @@ class PrevPredEmbeddings(_HipModule):
         assert prev_inds.dim() == 2 and prev_inds.dtype == torch.long and ans_emb.dim() == 2
         b, s = prev_inds.shape
         n_ans, n_ocr = ans_emb.size(0), ocr_emb.size(1)
-        ans = layer_norm(ans_emb, self.ans_layer_norm)                       # [V, D] bf16
-        ocr = layer_norm(ocr_emb, self.ocr_layer_norm).reshape(b * n_ocr, -1)  # [B*n_ocr, D]
-        is_ocr = prev_inds.ge(n_ans).view(torch.uint8).reshape(-1)          # token type: 1 for copied OCR tokens, sa_m4c.py:936
-        emb = EmbedLayerNormFn.apply(self.emb_layer_norm.weight, None, None, self.position_embeddings.weight, self.token_type_embeddings.weight,
-                                     is_ocr, b * s, s, self.emb_layer_norm, -1)
-        out = PrevPredGatherFn.apply(ans, ocr, emb, prev_inds, n_ocr, self.dropout_p if self.training else 0.0)
-        return out.view(b, s, -1)
+        out = PrevPredFn.apply(self.emb_layer_norm.weight, ans_emb, ocr_emb, prev_inds, self, self.dropout_p if self.training else 0.0)
+        return out
 
 
 class MMT(_HipModule):
@@ -603,11 +598,30 @@ class SAM4C(_HipModule):
         self._side_stream = None
         self.decode_cache = True      # eval-mode greedy loop re-runs only the decoder rows (set False for the reference's 12 full passes)
 
+    def _sam_param_rank(self, name):
+        """address order of the parameters inside their optimizer group (params.FlatParams): ascending address = LATER gradient, so that
+        the data-parallel buckets, walked from the end of the buffer, can leave in backward order.  word-embedding table (row-sparse
+        exchange) | object / OCR encoders (their backward runs last) | TextBert | pointer net, classifier | MMT."""
+        if name.startswith("text_bert.embeddings.word_embeddings"):
+            return 0
+        if name.startswith(("linear_obj", "obj_")):
+            return 1
+        if name.startswith(("linear_ocr", "ocr_feat", "ocr_bbox")):
+            return 2
+        if name.startswith("text_bert"):
+            return 3
+        if name.startswith("ocr_ptr_net"):
+            return 4
+        if name.startswith("classifier"):
+            return 5
+        return 6
+
     def _forward_obj_encoding(self, bd):
         feat = _pack_features([bd["pad_obj_features"]], self.normalize, 0)
         x = (layer_norm(linear(feat, self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
              + layer_norm(linear(_pack_features([bd["pad_obj_bboxes"][:, :, :-1]], False, 0), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
-        bd["obj_mmt_in"] = F.dropout(x, self.obj_drop_p, self.training)
+        x = F.dropout(x, self.obj_drop_p, self.training)
+        bd["obj_mmt_in"] = GradBarrierFn.apply(x, "obj") if self.training and torch.is_grad_enabled() else x
 
     def _forward_ocr_encoding(self, bd):
         ft, ph, fc = bd["ocr_fasttext"], bd["ocr_phoc"], bd["pad_ocr_features"]
@@ -616,11 +630,13 @@ class SAM4C(_HipModule):
         feat = _pack_features([ft, ph, fc] if self.mmt_config.use_phoc_fasttext else [fc], self.normalize, 50)
         x = (layer_norm(linear(feat, self.linear_ocr_feat_to_mmt_in), self.ocr_feat_layer_norm)
              + layer_norm(linear(_pack_features([bd["pad_ocr_bboxes"][:, :, :-1]], False, 0), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
-        bd["ocr_mmt_in"] = F.dropout(x, self.ocr_drop_p, self.training)
+        x = F.dropout(x, self.ocr_drop_p, self.training)
+        bd["ocr_mmt_in"] = GradBarrierFn.apply(x, "ocr") if self.training and torch.is_grad_enabled() else x
 
     def _forward_text_bert(self, bd):
         t = self.text_bert(bd)
-        bd["text_bert_emb"] = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+        t = t if isinstance(self.text_bert_out_linear, nn.Identity) else linear(t, self.text_bert_out_linear)
+        bd["text_bert_emb"] = GradBarrierFn.apply(t, "txt") if self.training and torch.is_grad_enabled() else t
 
     def _forward_mmt(self, bd):
         cache = bd.get("_sam_decode_cache")

@@ -36,6 +36,7 @@ class GradReducer:
         self.overlap = overlap and flat_grad.is_cuda and (self.world_size > 1 or self.force)
         self.stream = torch.cuda.Stream() if self.overlap else None
         self.regions = []
+        self.barrier_names, self.barrier_region = set(), None
         self.begin_step()
 
     def _build_buckets(self, cut):
@@ -56,6 +57,11 @@ class GradReducer:
         every registered region at or above its low end has reported `mark_done` (layers may finish in any order)."""
         order = sorted(range(len(ranges)), key=lambda i: -ranges[i][0])
         self.regions = [ranges[i] for i in order]
+        for (lo_hi, above) in zip(self.regions[1:], self.regions[:-1]):
+            if lo_hi[1] != above[0]:
+                raise ValueError("gradient regions must tile a contiguous range up to the end of the buffer: gap between %r and %r" % (lo_hi, above))
+        if self.regions and self.regions[0][1] != self.grad.numel():
+            raise ValueError("the highest gradient region must end at the end of the flat buffer")
         if self.regions:
             self._build_buckets(cut=min(lo for lo, _ in self.regions))
         ids = [0] * len(ranges)
@@ -64,18 +70,39 @@ class GradReducer:
         self.begin_step()
         return ids
 
+    def _note_stream(self):
+        if self.grad.is_cuda:
+            cur = torch.cuda.current_stream()
+            if all(cur != st for st in self.grad_streams):
+                self.grad_streams.append(cur)
+
     def mark_done(self, region_id):
+        self._note_stream()
         self.done[region_id] = True
         while self.done_ptr < len(self.regions) and self.done[self.done_ptr]:
             self.done_ptr += 1
         if self.done_ptr > 0:
             self.region_done(self.regions[self.done_ptr - 1][0])
 
+    def set_barrier(self, names, region_id):
+        """region `region_id` is final once every name in `names` has been reported by barrier_hit (autograd.GradBarrierFn)"""
+        self.barrier_names, self.barrier_region = set(names), region_id
+
+    def barrier_hit(self, name):
+        if self.barrier_region is None:
+            return
+        self._note_stream()
+        self.barrier_seen.add(name)
+        if self.barrier_names <= self.barrier_seen and not self.done[self.barrier_region]:
+            self.mark_done(self.barrier_region)
+
     def begin_step(self):
+        self.grad_streams = [torch.cuda.current_stream()] if self.grad.is_cuda else []
         self.next_bucket = 0
         self.ready_lo = self.grad.numel()      # gradients at addresses >= ready_lo are final
         self.work = []
         self.snapshots = []
+        self.barrier_seen = set()
         self.done = [False] * len(self.regions)
         self.done_ptr = 0
 
@@ -84,13 +111,20 @@ class GradReducer:
         chunk = self.grad[lo:hi]
         if self.world_size == 1 and not self.force:
             return
-        if self.check:
-            self.snapshots.append((k, chunk.clone()))
         if self.overlap:
-            self.stream.wait_stream(torch.cuda.current_stream())
+            # gradients are written on the stream the step started on and (TextBert) on a side stream, and a release may be triggered from
+            # either one for regions finished on the other: wait for every stream a finality mark was reported from -- everything the
+            # bucket needs was ENQUEUED before this call (host order), this makes it COMPLETE
+            self._note_stream()
+            for st in self.grad_streams:
+                self.stream.wait_stream(st)
             with torch.cuda.stream(self.stream):
+                if self.check:
+                    self.snapshots.append((k, chunk.clone()))
                 self.work.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
+            if self.check:
+                self.snapshots.append((k, chunk.clone()))
             dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
 
     def region_done(self, lo):

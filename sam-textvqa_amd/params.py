@@ -41,6 +41,10 @@ def _ordered_params(module):
     for p in module.parameters():
         for q in qkv_of.get(id(p), (p,)):
             add(q)
+    rank = getattr(module, "_sam_param_rank", None)       # optional address-order hint (SAM4C: backward order, see modules.py); stable sort
+    if rank is not None:
+        names = {id(p): n for n, p in module.named_parameters()}
+        order.sort(key=lambda p: rank(names[id(p)]))
     return order
 
 

@@ -46,12 +46,46 @@ class Trainer:
         if reducer is not None and parallel.dist.is_initialized() and dev.type == "cuda":
             parallel.dist.all_reduce(self.gnorm_sq)              # (zeros) creates the RCCL communicator here, not inside the first timed step
         if reducer is not None:
-            enc = getattr(getattr(model, "mmt", None), "encoder", None)
-            layers = [l for name in ("normal_layers", "spatial_layers", "implicit_layers") for l in getattr(enc, name, [])] if enc is not None else []
-            for layer, rid in zip(layers, reducer.register_regions([self.flat.range_of(l) for l in layers])):
-                layer._sam_region_id = rid
+            self._register_regions(reducer)
         self.global_step = 0
         dropout_clock.manual_seed(seed)
+
+    def _register_regions(self, reducer):
+        """Tell the reducer which address ranges become final at which explicit point of the backward pass, from the end of the buffer down
+        (SAM4C._sam_param_rank lays the parameters out in that order):
+          MMT encoder layers   -> EncoderLayerFn.backward of each layer
+          pointer net, classifier, PrevPredEmbeddings -> when the gradients of all three MMT inputs are complete (GradBarrierFn: every node
+                                  downstream of them, incl. the single-node PrevPredFn and the two nn.Linear heads, has run its backward)
+          TextBert layers      -> EncoderLayerFn.backward;   TextBert position / type / LayerNorm -> EmbedLayerNormFn.backward
+        Everything below (object / OCR encoders) leaves at finish(); the word-embedding table is exchanged row-sparsely.
+        Any piece that is missing or not where expected drops that region and everything below it (the ranges must tile up to the end)."""
+        model, flat = self.model, self.flat
+        enc = getattr(getattr(model, "mmt", None), "encoder", None)
+        layers = [l for name in ("normal_layers", "spatial_layers", "implicit_layers") for l in getattr(enc, name, [])] if enc is not None else []
+        if not layers:
+            return
+        ranges, owners = [flat.range_of(l) for l in layers], list(layers)
+        try:
+            lo_head, lo_enc = flat.range_of(model.ocr_ptr_net)[0], flat.range_of(enc)[0]
+            tb_layers = list(model.text_bert.encoder.layer)
+            tb_ranges = [flat.range_of(l) for l in tb_layers]
+            emb = model.text_bert.embeddings
+            lo_emb = flat.layout[emb.position_embeddings.weight._sam_index][0]
+            ok = (lo_enc == min(r[0] for r in ranges) and tb_ranges[-1][1] == lo_head and tb_ranges[0][0] > lo_emb
+                  and all(a[1] == b[0] for a, b in zip(tb_ranges[:-1], tb_ranges[1:]))
+                  and {emb.position_embeddings.weight._sam_index, emb.token_type_embeddings.weight._sam_index, emb.LayerNorm.weight._sam_index,
+                       emb.LayerNorm.bias._sam_index} == set(range(emb.position_embeddings.weight._sam_index, tb_layers[0].attention.self.query.weight._sam_index)))
+        except (AttributeError, ValueError, IndexError):
+            ok = False
+        if ok:
+            ranges += [(lo_head, lo_enc)] + tb_ranges + [(lo_emb, tb_ranges[0][0])]
+            owners += ["head"] + tb_layers + [emb.LayerNorm]
+        ids = reducer.register_regions(ranges)
+        for owner, rid in zip(owners, ids):
+            if owner == "head":
+                reducer.set_barrier(("txt", "obj", "ocr"), rid)
+            else:
+                owner._sam_region_id = rid
 
     def _sparse_table_end(self):
         """if the word-embedding table is the first parameter of flat storage (it is for SAM4C: text_bert comes first) its gradient is

@@ -283,11 +283,27 @@ for dist_on in (True, False):
         w = model.text_bert.embeddings.word_embeddings.weight
         assert tr.reducer.dense_lo == tr.flat.layout[1][0] >= w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
         assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo and tr.reducer.check
-        enc_lo = tr.flat.range_of(model.mmt.encoder)[0]
-        assert any(lo == enc_lo for lo, _ in tr.reducer.buckets)          # bucket boundary at the low end of the encoder layers
+        red = tr.reducer
+        # regions, from the end of the buffer down: 2 MMT layers | pointer net + classifier + PrevPredEmbeddings (barrier) | 1 TextBert layer | its embeddings
+        assert len(red.regions) == 5 and red.barrier_region == 2 and red.barrier_names == {"txt", "obj", "ocr"}
+        assert red.regions[0][1] == tr.flat.numel and all(a[0] == b[1] for a, b in zip(red.regions[:-1], red.regions[1:]))
+        assert red.regions[2] == (tr.flat.range_of(model.ocr_ptr_net)[0], tr.flat.range_of(model.mmt.encoder)[0])
+        assert any(lo == red.regions[-1][0] for lo, _ in red.buckets)     # bucket boundary at the low end of the regions
+        assert red.regions[-1][0] > tr.flat.range_of(model.linear_ocr_feat_to_mmt_in)[0] > tr.flat.range_of(model.linear_obj_feat_to_mmt_in)[0] >= red.dense_lo
     batch = make_batch(4, vocab=300, device="cuda", seed=21)
     batch["question_indices"] = batch["question_indices"] % 500
     losses = [tr.step(clone_batch(batch)).item() for _ in range(4)]
+    if dist_on:
+        assert all(tr.reducer.done) and tr.reducer.barrier_seen == {"txt", "obj", "ocr"}      # every finality mark fired during the last backward
+        red = tr.reducer                                     # the checker itself: release everything, then write late -> finish() must object
+        red.begin_step(); red.region_done(0)
+        tr.flat.grad[red.buckets[1][0] + 5] += 1.0
+        try:
+            red.finish()
+            raise SystemExit("SAM_REDUCER_CHECK missed a write after release")
+        except RuntimeError as e:
+            assert "released before" in str(e), e
+        red.begin_step(); tr.flat.zero_grad()
     res.append((losses, tr.flat.flat.clone()))
 torch.cuda.synchronize()
 (l1, p1), (l0, p0) = res

@@ -6,6 +6,7 @@ from sam_textvqa_amd import parallel
 from sam_textvqa_amd.synthetic import clone_batch, make_batch
 from sam_textvqa_amd.trainer import Trainer
 os.environ["SAM_FORCE_DIST"] = "1"
+os.environ["SAM_REDUCER_CHECK"] = "1"                   # every released bucket is re-checked at finish(): a premature release raises
 parallel.init_distributed()                               # 1-rank RCCL group: all-reduce / all-gather really go through RCCL
 res = []
 for dist_on in (True, False):
@@ -15,8 +16,10 @@ for dist_on in (True, False):
     assert (tr.reducer is not None) == dist_on
     if dist_on:
         w = model.text_bert.embeddings.word_embeddings.weight
-        assert tr.reducer.dense_lo == w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
-        assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo
+        assert tr.reducer.dense_lo == tr.flat.layout[1][0] >= w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
+        assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo and tr.reducer.check
+        enc_lo = tr.flat.range_of(model.mmt.encoder)[0]
+        assert any(lo == enc_lo for lo, _ in tr.reducer.buckets)          # bucket boundary at the low end of the encoder layers
     batch = make_batch(4, vocab=300, device="cuda", seed=21)
     batch["question_indices"] = batch["question_indices"] % 500
     losses = [tr.step(clone_batch(batch)).item() for _ in range(4)]
