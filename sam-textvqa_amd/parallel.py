@@ -21,8 +21,9 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0):
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0, scatter_fn=None):
         self.grad = flat_grad
+        self.scatter_fn = scatter_fn or _scatter_rows
         self.dense_lo = int(dense_lo)     # [0, dense_lo) is exchanged through sparse_rows(), not all-reduced
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -144,7 +145,7 @@ class GradReducer:
             dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group)
             dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=self.group)
             ids, rows = ids_all, rows_all
-        _scatter_rows(grad_table, ids, rows, padding_idx)
+        self.scatter_fn(grad_table, ids, rows, padding_idx)
 
     def finish(self):
         """after backward: reduce whatever is left, then make the compute stream wait for the exchange"""
@@ -164,12 +165,10 @@ class GradReducer:
 
 
 def _scatter_rows(grad_table, ids, rows, padding_idx):
-    if grad_table.is_cuda:
-        from . import ops
-        ops.embedding_bwd(rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16), ids, grad_table, padding_idx)
-    else:       # CPU tensors only occur in the gloo unit tests of this class
-        keep = ids != padding_idx
-        grad_table.index_add_(0, ids[keep], rows[keep].to(grad_table.dtype))
+    """grad_table[ids[t], :] += rows[t, :] on the GPU (sam_embedding_bwd); there is no CPU implementation in the package -- the gloo unit
+    test of GradReducer injects its own `scatter_fn`"""
+    from . import ops
+    ops.embedding_bwd(rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16), ids, grad_table, padding_idx)
 
 
 active_reducer = None   # set by the Trainer; EncoderLayerFn.backward reports finished layers to it
