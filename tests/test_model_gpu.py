@@ -328,3 +328,43 @@ def test_rccl_path_one_rank_matches_plain_trainer(tmp_path):
                HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _DIST_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_training_trajectory_matches_oracle_train_step():
+    """SURVEY §8a a-18 end to end: six optimisation steps (forward, masked BCE, backward, clip 0.25, Adam, LambdaLR warm-up) of the HIP
+    Trainer against the oracle's train_step (train.py:133-144 restated) from identical weights on identical batches, dropout off"""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    shapes = (20, 100, 50, 12)
+    model, ref = _small_full_model(3, ("n", "s"), shapes)
+    init = {k: v.clone() for k, v in ref.state_dict().items()}
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    opt, sched = O.make_optimizer(ref, base_lr=1e-3)
+    ref.train()
+    batches = []
+    for i in range(3):
+        bd = make_batch(3, *shapes, vocab=300, context=3, device="cpu", seed=40 + i)
+        bd["question_indices"] = (bd["question_indices"] % 499 + 1) * bd["question_mask"]
+        batches.append(bd)
+    to_gpu = lambda bd: {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd.items()}
+    l_hip, l_ref = [], []
+    for step in range(6):
+        bd = batches[step % 3]
+        l_ref.append(O.train_step(ref, clone_batch(bd), opt, sched).item())
+        l_hip.append(tr.step(to_gpu(clone_batch(bd))).item())
+    assert all(abs(a - b) <= 0.02 * abs(b) for a, b in zip(l_hip, l_ref)), (l_hip, l_ref)
+    assert l_ref[-1] < l_ref[0]
+    # where the optimiser took the parameters: direction and size of the total update, per tensor family
+    sd = tr.state_dict()["model_state_dict"]
+    cos, rel = [], []
+    for k, v0 in init.items():
+        d_ref, d_hip = (ref.state_dict()[k] - v0).flatten().double(), (sd[k].cpu() - v0).flatten().double()
+        if d_ref.norm() < 1e-6 or k.endswith(".key.bias"):       # key biases: softmax is invariant to them, their gradient is exactly 0 in
+            continue                                               # exact arithmetic and pure rounding noise otherwise (Adam turns noise into +-lr steps)
+        cos.append((k, float(torch.dot(d_ref, d_hip) / (d_ref.norm() * d_hip.norm() + 1e-30))))
+        rel.append(float((d_ref - d_hip).norm() / d_ref.norm()))
+    worst = min(cos, key=lambda t: t[1])
+    # Adam normalises every coordinate by its own gradient history: coordinates whose gradient is at the bf16 noise level take
+    # different +-lr steps, so agreement is asked of the bulk (median) and of the worst tensor's direction
+    assert worst[1] > 0.8, worst
+    assert sorted(c for _, c in cos)[len(cos) // 2] > 0.97 and sorted(rel)[len(rel) // 2] < 0.25
