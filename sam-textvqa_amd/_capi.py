@@ -70,13 +70,19 @@ class SamHipError(RuntimeError):
 
 
 def lib():
-    global _lib
+    global _lib, LIB_PATH
     if _lib is None:
+        alt = os.environ.get("SAM_HIP_LIB")          # tuning: load an alternative build of the same ABI (A/B runs inside one process tree)
+        if alt:
+            if not os.path.exists(alt):
+                raise SamHipError("SAM_HIP_LIB=%s does not exist" % alt)
+            LIB_PATH = alt
         # (re)build when the sources changed or the library is missing; a no-op (source hash compare) otherwise.  If that is
         # impossible (no hipcc) and no library exists, fail: there is no fallback path.
         try:
             from . import _build
-            _build.build()
+            if not alt:
+                _build.build()
         except Exception as e:
             if not os.path.exists(LIB_PATH):
                 raise SamHipError("libsam_hip.so is missing and could not be built (%s): run `python __graft_entry__.py`; "
