@@ -650,6 +650,22 @@ class SAM4C(_HipModule):
 
     def _forward_output(self, bd):
         dec = bd["mmt_dec_output"]
+        if self.training and self.overlap_text_bert and torch.is_grad_enabled():
+            # the two heads are independent chains of small kernels (768 decoder rows): the pointer network runs on the side stream next to
+            # the classifier, forward and (autograd replays the streams) backward
+            main = torch.cuda.current_stream()
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                dyn = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
+            bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
+            main.wait_stream(side)
+            dyn.record_stream(main)
+            bd["dynamic_ocr_scores"] = dyn
+            bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
+            return
         bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
         bd["dynamic_ocr_scores"] = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
         bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
