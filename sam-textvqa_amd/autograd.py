@@ -404,10 +404,14 @@ class BceLossFn(Function):
     """M4CDecodingBCEWithMaskLoss (sam/task_utils.py:19-30) on the two score blocks; gradient computed in the forward pass"""
 
     @staticmethod
-    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale, unit_grad=False):
+    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale, unit_grad=False, count_ratio=None):
         r = fixed.shape[0] * fixed.shape[1]
         f2, o2 = fixed.reshape(r, -1), ocr.reshape(r, -1)
         loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale)
+        if count_ratio is not None:          # data parallel: this rank's share of the global normaliser (device scalar, no host sync)
+            d_fixed.mul_(count_ratio.to(BF16))
+            d_ocr.mul_(count_ratio)
+            loss = loss * count_ratio
         ctx.save_for_backward(d_fixed, d_ocr)
         ctx.shapes, ctx.unit_grad = (fixed.shape, ocr.shape), unit_grad
         return loss[0]
@@ -416,5 +420,5 @@ class BceLossFn(Function):
     def backward(ctx, g):
         d_fixed, d_ocr = ctx.saved_tensors
         if ctx.unit_grad:      # the caller (Trainer.step) runs loss.backward() itself: upstream gradient is exactly 1, skip three elementwise passes
-            return d_fixed.view(ctx.shapes[0]), d_ocr.view(ctx.shapes[1]), None, None, None, None
-        return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None, None
+            return d_fixed.view(ctx.shapes[0]), d_ocr.view(ctx.shapes[1]), None, None, None, None, None
+        return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None, None, None

@@ -8,8 +8,9 @@ with overlap=True each bucket's all-reduce is issued on a side stream as soon as
 backward (EncoderLayerFn.backward calls `layer_done`), hiding the exchange behind the remaining backward GEMMs.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): large buckets (default 64 MB) keep RCCL's ring/tree per-link
 bound instead of latency bound; 386 MB of fp32 gradients = 6 buckets.
-The loss normaliser max(sum(loss_mask),1) is per rank here (per global batch under DataParallel, task_utils.py:28-29);
-gradients are pre-scaled by 1/world in the loss kernel so the all-reduce SUM is the mean of per-rank gradients.
+The loss normaliser max(sum(loss_mask),1) is the GLOBAL batch's, as under the reference's DataParallel (task_utils.py:28-29): every rank
+all-reduces its count (one float, underneath the forward pass) and scales its loss gradient by count_rank / count_global, so the all-reduce
+SUM of the per-rank gradients is the gradient of the global mean (Trainer.step).
 
 Sparse table: the 30522 x 768 word-embedding table is 94 MB of the 386 MB gradient buffer, touches at most B*20 rows per step and
 is the LAST gradient of the backward pass (nothing left to hide its exchange behind).  When it sits at the bottom of the flat buffer

@@ -19,11 +19,12 @@ def lr_lambda(it, warmup_iters=1000, warmup_factor=0.2, lr_decay_iters=(14000, 1
     return pow(lr_decay, bisect(list(lr_decay_iters), it))
 
 
-def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False):
+def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, count_ratio=None):
     """M4CDecodingBCEWithMaskLoss on the score blocks SAM4C.forward left in batch_dict.  unit_grad=True: the caller promises to call
-    .backward() on the returned loss with the default gradient of 1 (the loss gradient is then handed on without being rescaled)"""
+    .backward() on the returned loss with the default gradient of 1 (the loss gradient is then handed on without being rescaled).
+    count_ratio: device scalar count_rank / count_global (data parallel, see Trainer.step): loss and gradient are scaled by it"""
     return BceLossFn.apply(batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"], batch_dict["targets"], batch_dict["train_loss_mask"], grad_scale,
-                           unit_grad)
+                           unit_grad, count_ratio)
 
 
 class Trainer:
@@ -108,9 +109,20 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.begin_step()
         parallel.active_reducer = self.reducer
+        ratio = None
+        if self.reducer is not None and parallel.dist.is_initialized():
+            # the reference normalises the loss by the number of unmasked decoding steps of the WHOLE batch (nn.DataParallel gathers the
+            # scores before the loss, task_utils.py:28-29): every rank contributes its count now (the all-reduce of one float runs
+            # underneath the forward pass) and scales its loss gradient by count_rank / count_global, so that the all-reduce SUM of the
+            # per-rank gradients is exactly the gradient of the global mean
+            c_local = batch_dict["train_loss_mask"].to(device=flat.grad.device, dtype=torch.float32).sum().clamp_(min=1.0).reshape(1)
+            c_global = c_local.clone()
+            work = parallel.dist.all_reduce(c_global, async_op=True)
         model(batch_dict)
-        grad_scale = 1.0 / self.reducer.world_size if self.reducer is not None else 1.0
-        loss = masked_bce_loss(batch_dict, grad_scale, unit_grad=True)
+        if self.reducer is not None and parallel.dist.is_initialized():
+            work.wait()
+            ratio = c_local / c_global
+        loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, count_ratio=ratio)
         loss.backward()
         parallel.active_reducer = None
         if self.reducer is not None:

@@ -102,3 +102,13 @@ def test_sparse_table_exchange_gloo_world2():
         p.join(60)
         assert p.exitcode == 0
     assert res == [(0, True), (1, True)]
+
+
+def test_global_loss_normaliser_identity():
+    """Trainer.step's data-parallel scaling: sum_r (c_r / C) * mean_r(grad) == global mean gradient, for unequal per-rank counts"""
+    g = torch.Generator().manual_seed(0)
+    per_rank = [torch.randn(n, 5, generator=g) for n in (7, 1, 12)]            # per-sample "gradients" of the unmasked steps of 3 ranks
+    counts = torch.tensor([float(len(x)) for x in per_rank])
+    total = counts.sum()
+    ddp = sum((c / total) * x.mean(0) for c, x in zip(counts, per_rank))
+    assert torch.allclose(ddp, torch.cat(per_rank).mean(0), atol=1e-6)
