@@ -274,7 +274,8 @@ class PrevPredFn(Function):
         dx_ocr, _ = ops.layernorm_bwd(d_ocr.to(BF16), ocr_x, m_o, r_o, ln.weight, ln.weight.grad, ln.bias.grad)
         g_ans = None
         if getattr(ans_param, "_sam_flat", None) is not None and ans_param.grad is not None:
-            ans_param.grad.add_(dx_ans)                       # prepared parameter (the classifier weight): accumulate here, not through autograd
+            ans_param.grad.add_(dx_ans.float())               # prepared parameter (the classifier weight): accumulate here, not through autograd
+                                                              # (cast first: torch's mixed bf16 -> fp32 in-place add runs at a quarter of the speed)
         elif ctx.needs_input_grad[1]:
             g_ans = dx_ans.to(ans_param.dtype)
         g_ocr = dx_ocr.view(ocr_shape).to(ocr_dtype) if ctx.needs_input_grad[2] else None
