@@ -131,6 +131,15 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_raw_stream = None
+
+
 def stream_handle():
+    """hipStream_t of torch's current stream on the current device (the raw-handle getter: ~1 us instead of ~10 us for building a
+    torch.cuda.Stream object, 500 times per step)"""
+    global _raw_stream
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _raw_stream is None:
+        get, dev = getattr(torch._C, "_cuda_getCurrentRawStream", None), getattr(torch._C, "_cuda_getDevice", None)
+        _raw_stream = (lambda: get(dev())) if get and dev else (lambda: torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(_raw_stream())

@@ -167,7 +167,7 @@ _WS = {}
 def _workspace(nbytes, device, tag):
     """per-(device, stream, tag) scratch that only grows; the kernels that use one buffer are ordered by its stream (TextBert runs on a
     side stream next to the object / OCR encoders: each stream gets its own scratch)"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream, tag)
+    key = (device, capi.stream_handle().value, tag)
     buf = _WS.get(key)
     if buf is None or buf.numel() * 4 < nbytes:
         buf = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)

@@ -104,7 +104,8 @@ class Trainer:
     def step(self, batch_dict):
         """one optimisation step; returns the (device, un-synchronised) loss tensor"""
         model, flat = self.model, self.flat
-        model.train()
+        if not model.training:
+            model.train()                                        # (recursing over ~160 modules costs 0.6 ms of host time: only when needed)
         flat.zero_grad()
         if self.reducer is not None:
             self.reducer.begin_step()
