@@ -368,3 +368,48 @@ def test_training_trajectory_matches_oracle_train_step():
     # different +-lr steps, so agreement is asked of the bulk (median) and of the worst tensor's direction
     assert worst[1] > 0.8, worst
     assert sorted(c for _, c in cos)[len(cos) // 2] > 0.97 and sorted(rel)[len(rel) // 2] < 0.25
+
+
+def test_sam4c_degenerate_samples_vs_oracle():
+    """edge cases the reference's data can produce: an image with no OCR token and no object (everything padded), a one-word question,
+    a sample whose decoding steps are all masked out of the loss, and an answer made only of copied OCR tokens"""
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import masked_bce_loss
+    shapes = (20, 100, 50, 12)
+    model, ref = _small_full_model(3, ("n", "s", "s"), shapes)
+    bd_cpu = make_batch(4, *shapes, vocab=300, context=3, device="cpu", seed=23)
+    bd_cpu["pad_obj_mask"][0] = 0
+    bd_cpu["pad_ocr_mask"][0] = 0                                       # sample 0: nothing to look at but the question
+    bd_cpu["question_mask"][1] = 0
+    bd_cpu["question_mask"][1, 0] = 1                                   # sample 1: one-word question
+    bd_cpu["train_loss_mask"][2] = 0                                    # sample 2: contributes nothing to the loss
+    bd_cpu["train_prev_inds"][3, 1:] = 300 + torch.arange(11) % 50      # sample 3: every previous prediction is a copied OCR token
+    bd_cpu["question_indices"] = (bd_cpu["question_indices"] % 499 + 1) * bd_cpu["question_mask"]
+    ref.train()
+    out_ref = ref(clone_batch(bd_cpu))["textvqa_scores"]
+    loss_ref = O.m4c_decoding_bce_with_mask_loss(out_ref, bd_cpu["targets"], bd_cpu["train_loss_mask"])
+    loss_ref.backward()
+    model.cuda().train()
+    fp = prepare(model)
+    bd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd_cpu.items()}
+    fp.zero_grad()
+    out = model(bd)["textvqa_scores"]
+    loss = masked_bce_loss(bd)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(fp.grad).all()
+    assert rel_err(out, out_ref.detach()) < 0.03
+    assert abs(loss.item() - loss_ref.item()) < 0.01 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    assert (out[0, :, 300:] < -9000).all()                               # no OCR token: every pointer score is the literal -10000
+    refp = dict(ref.named_parameters())
+    biggest = max(p.grad.norm().item() for p in ref.parameters() if p.grad is not None)
+    bad = []
+    for pn, p in model.named_parameters():
+        g_ref = refp[pn].grad
+        if g_ref is None or g_ref.norm().item() < 1e-5 * biggest:
+            continue
+        e = ((p.grad.cpu().double() - g_ref.double()).norm() / g_ref.double().norm()).item()
+        if e > 0.05:
+            bad.append((pn, round(e, 4)))
+    assert not bad, bad
