@@ -206,28 +206,6 @@ class EmbedLayerNormFn(Function):
         return (None,) * 10
 
 
-class PrevPredGatherFn(Function):
-    """(ind < V ? ans[ind] : ocr[b, ind - V]) + dropout(emb): _batch_gather over cat([ans_emb, ocr_emb]) and the final sum of
-    PrevPredEmbeddings.forward, sam/sa_m4c.py:921-948, one launch each way (the reference materialises a [B, V + n_ocr, D] table)."""
-
-    @staticmethod
-    def forward(ctx, ans, ocr2d, emb, inds, n_ocr, p_drop):
-        ctx.seed = dropout_clock.next()
-        ctx.cfg = (ans.shape[0], n_ocr, p_drop)
-        inds = inds.contiguous()
-        ctx.save_for_backward(inds)
-        return ops.gather2_add_fwd(ans.contiguous(), ocr2d.contiguous(), inds, n_ocr, emb.contiguous(), p_drop, *ctx.seed)
-
-    @staticmethod
-    def backward(ctx, dy):
-        (inds,) = ctx.saved_tensors
-        v, n_ocr, p_drop = ctx.cfg
-        if dy.dtype != BF16 or not dy.is_contiguous():
-            dy = dy.to(BF16).contiguous()
-        d_ans, d_ocr, d_emb = ops.gather2_add_bwd(dy, inds, v, n_ocr, ctx.needs_input_grad[2], p_drop, *ctx.seed)
-        return d_ans, d_ocr, d_emb, None, None, None
-
-
 class PrevPredFn(Function):
     """PrevPredEmbeddings.forward (sam/sa_m4c.py:900-948) as ONE autograd node:
         LN_ans(ans_emb)[ind] or LN_ocr(ocr_emb)[b, ind - V]  +  dropout(LN_emb(pos[s] + type[ind >= V]))
