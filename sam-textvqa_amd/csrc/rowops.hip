@@ -371,8 +371,13 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
 #pragma unroll
     for (int s = 7; s >= 0; --s)
       if (s < segs.n && e0 < segs.end[s]) lr = segs.lr[s];
-    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
-    float4 p4 = reinterpret_cast<float4*>(p)[i], m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i];
+    // streaming access: every byte is touched once per step, nontemporal loads/stores keep 2.9 GB from churning the L2 / Infinity Cache
+    // (538 -> 497 us, 5.4 -> 5.85 TB/s, A/B on one box)
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f g_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(g) + i), p_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p) + i),
+              m_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(m) + i), v_ = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(v) + i);
+    const float4 g4 = make_float4(g_[0], g_[1], g_[2], g_[3]);
+    float4 p4 = make_float4(p_[0], p_[1], p_[2], p_[3]), m4 = make_float4(m_[0], m_[1], m_[2], m_[3]), v4 = make_float4(v_[0], v_[1], v_[2], v_[3]);
     const float gg[4] = {g4.x * clip, g4.y * clip, g4.z * clip, g4.w * clip};
     float pp[4] = {p4.x, p4.y, p4.z, p4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
@@ -382,9 +387,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
       const float denom = sqrtf(vv[e]) * rsqrt_bc2 + eps;
       pp[e] -= (lr / bc1) * (mm[e] / denom);
     }
-    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
-    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
-    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    __builtin_nontemporal_store((v4f){pp[0], pp[1], pp[2], pp[3]}, reinterpret_cast<v4f*>(p) + i);
+    __builtin_nontemporal_store((v4f){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<v4f*>(m) + i);
+    __builtin_nontemporal_store((v4f){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<v4f*>(v) + i);
     if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3]));
   }
 }
