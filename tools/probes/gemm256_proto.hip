@@ -5,7 +5,7 @@
 // one wave per SIMD the schedule is everything: BK=64 double buffer, scheduler's own order: 447 TFLOP/s at 11648x3072x768 (768 at 8192^3);
 // BK=32 4-stage ring with counted vmcnt + fragment prefetch forced by sched_group_barrier: 514 / 571 (N=2304) / 678 (K=3072) / 842 (8192^3).
 // The library's 2x2-wave kernels of this shape reach 890-1100 on the same problems, ours (2 blocks x 4 waves of 96x64) 670-910: the
-// register tile alone does not pay without the hand-placed 8-phase schedule.
+// register tile alone does not pay without the hand-placed 8-phase schedule.  (Same ring with 8 waves of 128x64: 545 / 607 / 703 / 850.)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I sam-textvqa_amd/csrc -I include tools/probes/gemm256_proto.hip -o tools/probes/gemm256_proto
 //   tools/probes/gemm256_proto [M N K]
 #include <hip/hip_runtime.h>
