@@ -184,7 +184,11 @@ def init_distributed():
     if (world > 1 or os.environ.get("SAM_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29577")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # SAM_DIST_BACKEND=gloo + SAM_DIST_SHARE_GPU=1: several ranks on ONE GPU through gloo's CUDA-tensor collectives -- how the multi-rank
+        # logic (bucket release, row-sparse exchange, global loss normaliser, replica consistency) is tested end to end on a 1-GPU box
+        backend = os.environ.get("SAM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if os.environ.get("SAM_DIST_SHARE_GPU") == "1":
+            local = 0
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}

@@ -1,0 +1,103 @@
+"""Two data-parallel ranks on ONE GPU (gloo's CUDA-tensor collectives stand in for RCCL; everything above the transport is the product
+path: bucketed overlapped all-reduce with finality regions, row-sparse word-embedding exchange, global loss normaliser): the two replicas
+must stay identical and must follow the single-process run on the concatenated batch -- the reference's nn.DataParallel semantics."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+SHAPES = (20, 100, 50, 12)
+STEPS = 4
+
+
+def _slice_batch(bd, lo, hi):
+    out = {}
+    for k, v in bd.items():
+        if torch.is_tensor(v):
+            out[k] = v[lo:hi].contiguous()
+        elif isinstance(v, dict):
+            out[k] = {kk: vv[lo:hi].contiguous() for kk, vv in v.items()}
+        else:
+            out[k] = v
+    return out
+
+
+def _global_batches():
+    from sam_textvqa_amd.synthetic import make_batch
+    out = []
+    for i in range(2):
+        bd = make_batch(8, *SHAPES, vocab=300, context=3, device="cpu", seed=70 + i)
+        bd["question_indices"] = (bd["question_indices"] % 499 + 1) * bd["question_mask"]
+        bd["train_loss_mask"][1, 6:] = 0          # unequal numbers of unmasked decoding steps on the two ranks
+        bd["train_loss_mask"][5] = 0
+        out.append(bd)
+    return out
+
+
+def _to_gpu(bd):
+    return {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in bd.items()}
+
+
+def _run(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1")
+    from sam_textvqa_amd import parallel
+    from sam_textvqa_amd.synthetic import clone_batch
+    from sam_textvqa_amd.trainer import Trainer
+    from tests.test_model_gpu import _small_full_model
+    if world > 1:
+        parallel.init_distributed()
+    model, _ = _small_full_model(3, ("n", "s"), SHAPES)
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    assert (tr.reducer is not None) == (world > 1)
+    if world > 1:
+        assert tr.reducer.world_size == world and tr.reducer.overlap and tr.reducer.dense_lo > 0 and len(tr.reducer.regions) == 5
+    losses = []
+    per = 8 // world
+    for step in range(STEPS):
+        bd = _slice_batch(_global_batches()[step % 2], rank * per, (rank + 1) * per)
+        losses.append(tr.step(_to_gpu(clone_batch(bd))).item())
+    torch.cuda.synchronize()
+    torch.save((rank, losses, tr.flat.flat.cpu(), tr.exp_avg_sq.cpu()), os.path.join(out_dir, "w%d_r%d.pt" % (world, rank)))
+    if world > 1:
+        parallel.dist.barrier()
+        parallel.dist.destroy_process_group()
+
+
+def _spawn(world, out_dir):
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_run, args=(r, world, port, str(out_dir))) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    return [torch.load(os.path.join(str(out_dir), "w%d_r%d.pt" % (world, r))) for r in range(world)]
+
+
+def test_two_ranks_match_each_other_and_the_global_batch_run(tmp_path):
+    (r0, l0, p0, v0), (r1, l1, p1, v1) = _spawn(2, tmp_path)
+    (_, lg, pg, vg), = _spawn(1, tmp_path)
+    # replicas: same reduced gradients, same deterministic optimizer -> same parameters (the only freedom is the fp32-atomics order of the
+    # two scatter kernels, each rank scattering all ranks' rows)
+    assert (p0 - p1).abs().max().item() < 1e-4 and (v0 - v1).abs().max().item() < 1e-6, ((p0 - p1).abs().max().item(), (v0 - v1).abs().max().item())
+    # DataParallel semantics: sum of the ranks' (count-weighted) losses == loss of the concatenated batch, step by step
+    for a, b, g in zip(l0, l1, lg):
+        assert abs((a + b) - g) <= 2e-3 * abs(g), (l0, l1, lg)
+    # ... and the same trajectory: total parameter update of rank 0 vs the single-process run
+    from tests.test_model_gpu import _small_full_model
+    from sam_textvqa_amd.trainer import Trainer
+    init = None
+    # reconstruct the common initial point: both runs start from _small_full_model(seed 0); use the single run's first-step-independent init
+    model, _ = _small_full_model(3, ("n", "s"), SHAPES)
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    init = tr.flat.flat.cpu()
+    u_dp, u_g = (p0 - init).double(), (pg - init).double()
+    moved = u_g.abs() > 0
+    cos = float(torch.dot(u_dp[moved], u_g[moved]) / (u_dp[moved].norm() * u_g[moved].norm()))
+    rel = float((u_dp - u_g).norm() / u_g.norm())
+    assert cos > 0.98 and rel < 0.2, (cos, rel)
