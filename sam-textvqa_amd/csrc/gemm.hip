@@ -10,36 +10,11 @@
 // template without any transpose pass through HBM.
 // The MFMA is issued "transposed" (rows = n, cols = m) so each lane ends up with 4 CONSECUTIVE n of one
 // output row: bias/residual/aux are 8- or 16-byte vector accesses and stores are 8 B (bf16) / 16 B (fp32).
-#include <type_traits>
-#include "common.h"
-#include "sam_hip.h"
+#include "gemm_common.h"
 #include <stdlib.h>
-#ifndef SAM_GEMM_SC1_STORES
-#define SAM_GEMM_SC1_STORES 0   // measured: no gain (within noise) on any shape of the step; kept as a build-time switch
-#endif
 
+using namespace samgemm;
 namespace {
-
-constexpr int BK = 64;
-
-struct GemmArgs {
-  int M, N, K;
-  const bf16_t* A; int64_t lda;
-  const bf16_t* B; int64_t ldb;
-  void* C; int64_t ldc;
-  const float* bias;
-  const bf16_t* residual; int64_t ldr;
-  bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux;
-  int accumulate;
-  unsigned thr16; float inv_keep;
-  unsigned seed_lo, seed_hi, off_lo, off_hi;
-  int tiles_m, tiles_n, group_m;
-  int split_k;        // >1: grid = tiles * split_k; split s stores its fp32 partial tile into ws[s] (wgrad: few tiles, very long K)
-  float* ws;          // [split_k][M*N] partial outputs, then [split_k][M] partial bias gradients; reduced by splitk_reduce_kernel
-  float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
-  int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
-  int* split_used;    // host pointer: receives the split factor actually launched
-};
 
 // ---- LDS images (one 64-deep k-tile) -----------------------------------------------------------------
 // k-contiguous operand: [R rows][64 k] bf16, 128-byte rows, 16-byte chunk c stored at c ^ ((row>>1)&7)
@@ -119,29 +94,6 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, 
     return cat4(lds_read_tr16(p), lds_read_tr16(p + 4 * 2 * R));
   }
 }
-
-template <typename OutT> struct Store4;
-template <> struct Store4<bf16_t> {
-  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int) {
-    const uint2 val = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-#if SAM_GEMM_SC1_STORES
-    // write-through store: the output tile is never re-read by this kernel, keep it from evicting operand panels in the XCD's L2
-    const bf16_t* addr = reinterpret_cast<bf16_t*>(C) + idx;
-    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(addr), "v"(val) : "memory");
-#else
-    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + idx) = val;
-#endif
-  }
-};
-template <> struct Store4<float> {
-  // accumulate: 0 = store, 1 = read-modify-write (every element has exactly one writer)
-  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int accumulate) {
-    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx);
-    float4 o = make_float4(v[0], v[1], v[2], v[3]);
-    if (accumulate) { const float4 c = *p; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
-    *p = o;
-  }
-};
 
 // Tile configuration: BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
 //   <128,128,2,2>: 256 threads, 64 KB LDS, 2 blocks/CU  -- 64 flop per byte staged
@@ -245,93 +197,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
   int64_t ldc = p.ldc;
   int accumulate = p.accumulate;
   if (p.split_k > 1) { Cout = p.ws + (int64_t)split * p.M * p.N; ldc = p.N; accumulate = 0; }
-  // epilogue: lane owns rows m = m0 + wm*(BM/WM) + tm*16 + i, columns n = n0 + wn*(BN/WN) + tn*16 + 4g .. +3.
-  // Every global operand of the epilogue (bias, residual, GELU pre-activation) is fetched up front for ALL fragments, unconditionally
-  // at clamped addresses: a load under a per-lane predicate compiles to branch + s_waitcnt vmcnt(0), i.e. TM*TN dependent HBM round
-  // trips per wave (24 for the 192x128 tile) instead of one.
-  // Interior tiles (wave-uniform test) run the epilogue with no per-lane predicate at all: under a predicate the compiler sinks each
-  // fragment's arithmetic into the guarded block and opens it with s_waitcnt vmcnt(0), which also waits for the PREVIOUS fragment's
-  // store -- TM*TN serialized store round trips.  Edge tiles take the same code with clamped loads and guarded stores.
-  const int n_last = max(p.N - 4, 0), m_last = p.M - 1;
-  auto epilogue = [&](auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
-  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
-  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
-  float4 b4[TN];
-  uint2 pre[HAS_PRE ? TM : 1][HAS_PRE ? TN : 1];
-  if (HAS_BIAS) {
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      b4[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) b4[tn] = *reinterpret_cast<const float4*>(p.bias + (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
-    }
-  }
-  if (HAS_PRE) {
-    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
-    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn) pre[tm][tn] = make_uint2(0u, 0u);
-    if (src)
-#pragma unroll
-      for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
-          pre[tm][tn] = *reinterpret_cast<const uint2*>(src + (int64_t)(FULL ? m0 + wm * (BM / WM) + tm * 16 + i : min(m0 + wm * (BM / WM) + tm * 16 + i, m_last)) * lds_ +
-                                                        (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
-  }
-  constexpr bool F32_OUT = sizeof(OutT) == 4 && TM * TN <= 16;   // (the 256-wide test tiles keep the per-fragment read-modify-write: no registers left)
-  float4 cpre[F32_OUT ? TM : 1][F32_OUT ? TN : 1];    // accumulate=1 (wgrad into the gradient buffer): the old C values, same batching
-  if (F32_OUT && accumulate) {
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm)
-#pragma unroll
-      for (int tn = 0; tn < TN; ++tn)
-        cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0] = *reinterpret_cast<const float4*>(
-            reinterpret_cast<const float*>(Cout) + (int64_t)(FULL ? m0 + wm * (BM / WM) + tm * 16 + i : min(m0 + wm * (BM / WM) + tm * 16 + i, m_last)) * ldc + (FULL ? n0 + wn * (BN / WN) + tn * 16 + 4 * g : min(n0 + wn * (BN / WN) + tn * 16 + 4 * g, n_last)));
-  }
-#pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    const int m = m0 + wm * (BM / WM) + tm * 16 + i;
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-      const int n = n0 + wn * (BN / WN) + tn * 16 + 4 * g;
-      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
-      if (F32_OUT && accumulate) {
-        const float4 c = cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0];
-        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
-      }
-      if (HAS_BIAS) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
-      if (EPI == SAM_EPI_BIAS_GELU) {
-        if (FULL || (m < p.M && n < p.N))
-          *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-      }
-      if (EPI == SAM_EPI_DGELU) {
-        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];
-        v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
-        v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
-      }
-      if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
-        if (p.thr16) {
-          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
-          const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
-          v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
-          v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
-          v[2] = (hi & 0xffffu) >= p.thr16 ? v[2] * p.inv_keep : 0.f;
-          v[3] = (hi >> 16) >= p.thr16 ? v[3] * p.inv_keep : 0.f;
-        }
-        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];   // zeros when there is no residual
-        v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
-      }
-      if (FULL || (m < p.M && n < p.N)) Store4<OutT>::st(Cout, (int64_t)m * ldc + n, v, F32_OUT ? 0 : accumulate);
-    }
-  }
-  };
-  if (m0 + BM <= p.M && n0 + BN <= p.N) epilogue(std::true_type{});
-  else epilogue(std::false_type{});
+  gemm_epilogue<TM, TN, EPI, OutT>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), m0 + BM <= p.M && n0 + BN <= p.N, Cout, ldc, accumulate, i, g);
 }
 
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
@@ -489,6 +355,16 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
   const int kt = (a.K + BK - 1) / BK;
   const int64_t per_split = ((int64_t)a.M * a.N + a.M) * (int64_t)sizeof(float);
   const int tn = (a.N + 127) / 128;
+  if (want_split == 0 && (force_tile == 0 || force_tile >= 1000)) {
+    // large problems: the 8-wave persistent kernels (gemm8.hip); they decline (SAM_ERR_UNSUPPORTED) what they have no instance for
+    static int v2 = -1;
+    if (v2 < 0) { const char* e = getenv("SAM_GEMM8"); v2 = e ? atoi(e) : 1; }
+    if (v2 || force_tile >= 1000) {
+      const int rc = gemm8_launch(a, (AKC ? 2 : 0) | (BKC ? 1 : 0), EPI, sizeof(OutT) == 4, force_tile, st);
+      if (rc != SAM_ERR_UNSUPPORTED) { if (a.split_used) *a.split_used = 1; return rc; }
+      if (force_tile >= 1000) { sam_set_error("sam_gemm_bf16: force_tile=%d: the 8-wave kernels have no instance for this problem", force_tile); return rc; }
+    }
+  }
   if (force_tile == 256) {
     a.tiles_m = (a.M + 255) / 256; a.tiles_n = (a.N + 255) / 256;
     if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 1, per_split, ws_bytes);
@@ -660,7 +536,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192 or 256");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192 or 1256");
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T

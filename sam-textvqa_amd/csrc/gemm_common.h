@@ -1,0 +1,267 @@
+// Shared pieces of the bf16 GEMM family (gemm.hip: 4-wave kernels; gemm8.hip: 8-wave persistent kernels): argument block, output stores,
+// and the fused epilogue.  Internal to the library (the C ABI is include/sam_hip.h).
+#pragma once
+#include <type_traits>
+#include "common.h"
+#include "sam_hip.h"
+#ifndef SAM_GEMM_SC1_STORES
+#define SAM_GEMM_SC1_STORES 0   // measured: no gain (within noise) on any shape of the step; kept as a build-time switch
+#endif
+
+namespace samgemm {
+
+constexpr int BK = 64;
+
+struct GemmArgs {
+  int M, N, K;
+  const bf16_t* A; int64_t lda;
+  const bf16_t* B; int64_t ldb;
+  void* C; int64_t ldc;
+  const float* bias;
+  const bf16_t* residual; int64_t ldr;
+  bf16_t* aux_out; const bf16_t* aux_in; int64_t ld_aux;
+  int accumulate;
+  unsigned thr16; float inv_keep;
+  unsigned seed_lo, seed_hi, off_lo, off_hi;
+  int tiles_m, tiles_n, group_m;
+  int split_k;        // >1: grid = tiles * split_k; split s stores its fp32 partial tile into ws[s] (wgrad: few tiles, very long K)
+  float* ws;          // [split_k][M*N] partial outputs, then [split_k][M] partial bias gradients; reduced by splitk_reduce_kernel
+  float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
+  int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
+  int* split_used;    // host pointer: receives the split factor actually launched
+};
+
+template <typename OutT> struct Store4;
+template <> struct Store4<bf16_t> {
+  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int) {
+    const uint2 val = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#if SAM_GEMM_SC1_STORES
+    // write-through store: the output tile is never re-read by this kernel, keep it from evicting operand panels in the XCD's L2
+    const bf16_t* addr = reinterpret_cast<bf16_t*>(C) + idx;
+    asm volatile("global_store_dwordx2 %0, %1, off sc1" ::"v"(addr), "v"(val) : "memory");
+#else
+    *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(C) + idx) = val;
+#endif
+  }
+};
+template <> struct Store4<float> {
+  // accumulate: 0 = store, 1 = read-modify-write (every element has exactly one writer)
+  static __device__ __forceinline__ void st(void* C, int64_t idx, const float* v, int accumulate) {
+    float4* p = reinterpret_cast<float4*>(reinterpret_cast<float*>(C) + idx);
+    float4 o = make_float4(v[0], v[1], v[2], v[3]);
+    if (accumulate) { const float4 c = *p; o.x += c.x; o.y += c.y; o.z += c.z; o.w += c.w; }
+    *p = o;
+  }
+};
+
+// Fused epilogue of one wave's TM x TN fragment grid.  acc[tn][tm] comes from mfma(B fragment, A fragment): lane (i = lane & 15, g = lane >> 4)
+// owns row m = mw + tm*16 + i and the four consecutive columns n = nw + tn*16 + 4g .. +3.
+// Every global operand of the epilogue (bias, residual, GELU pre-activation, old C) is fetched up front for ALL fragments, unconditionally
+// at clamped addresses: a load under a per-lane predicate compiles to branch + s_waitcnt vmcnt(0), i.e. TM*TN dependent HBM round
+// trips per wave instead of one.  Interior tiles (FULL) run with no per-lane predicate at all: under a predicate the compiler sinks each
+// fragment's arithmetic into the guarded block and opens it with s_waitcnt vmcnt(0), which also waits for the PREVIOUS fragment's
+// store -- TM*TN serialized store round trips.  Edge tiles take the same code with clamped loads and guarded stores.
+// (rows are handled in fragment-row ranges [T0, T1): the 8-wave kernels with 32 fragments per wave run two halves to bound the prefetch registers)
+template <int TM, int TN, int EPI, typename OutT, bool FULL, int T0 = 0, int T1 = TM, int N0 = 0, int N1 = TN>
+__device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, void* Cout, int64_t ldc, int accumulate, int i, int g) {
+  const int n_last = max(p.N - 4, 0), m_last = p.M - 1;
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  float4 b4[TN];
+  uint2 pre[HAS_PRE ? TM : 1][HAS_PRE ? TN : 1];   // (only rows [T0, T1) are touched: the rest is never materialised)
+  if (HAS_BIAS) {
+#pragma unroll
+    for (int tn = N0; tn < N1; ++tn) {
+      b4[tn] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) b4[tn] = *reinterpret_cast<const float4*>(p.bias + (FULL ? nw + tn * 16 + 4 * g : min(nw + tn * 16 + 4 * g, n_last)));
+    }
+  }
+  if (HAS_PRE) {
+    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
+    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
+#pragma unroll
+    for (int tm = T0; tm < T1; ++tm)
+#pragma unroll
+      for (int tn = N0; tn < N1; ++tn) pre[tm][tn] = make_uint2(0u, 0u);
+    if (src)
+#pragma unroll
+      for (int tm = T0; tm < T1; ++tm)
+#pragma unroll
+        for (int tn = N0; tn < N1; ++tn)
+          pre[tm][tn] = *reinterpret_cast<const uint2*>(src + (int64_t)(FULL ? mw + tm * 16 + i : min(mw + tm * 16 + i, m_last)) * lds_ +
+                                                        (FULL ? nw + tn * 16 + 4 * g : min(nw + tn * 16 + 4 * g, n_last)));
+  }
+  constexpr bool F32_OUT = sizeof(OutT) == 4 && (T1 - T0) * TN <= 16;   // (the 256-wide test tiles keep the per-fragment read-modify-write: no registers left)
+  float4 cpre[F32_OUT ? TM : 1][F32_OUT ? TN : 1];    // accumulate=1 (wgrad into the gradient buffer): the old C values, same batching
+  if (F32_OUT && accumulate) {
+#pragma unroll
+    for (int tm = T0; tm < T1; ++tm)
+#pragma unroll
+      for (int tn = N0; tn < N1; ++tn)
+        cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0] = *reinterpret_cast<const float4*>(
+            reinterpret_cast<const float*>(Cout) + (int64_t)(FULL ? mw + tm * 16 + i : min(mw + tm * 16 + i, m_last)) * ldc + (FULL ? nw + tn * 16 + 4 * g : min(nw + tn * 16 + 4 * g, n_last)));
+  }
+#pragma unroll
+  for (int tm = T0; tm < T1; ++tm) {
+    const int m = mw + tm * 16 + i;
+#pragma unroll
+    for (int tn = N0; tn < N1; ++tn) {
+      const int n = nw + tn * 16 + 4 * g;
+      float v[4] = {acc[tn][tm][0], acc[tn][tm][1], acc[tn][tm][2], acc[tn][tm][3]};
+      if (F32_OUT && accumulate) {
+        const float4 c = cpre[F32_OUT ? tm : 0][F32_OUT ? tn : 0];
+        v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w;
+      }
+      if (HAS_BIAS) { v[0] += b4[tn].x; v[1] += b4[tn].y; v[2] += b4[tn].z; v[3] += b4[tn].w; }
+      if (EPI == SAM_EPI_BIAS_GELU) {
+        if (FULL || (m < p.M && n < p.N))
+          *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+      }
+      if (EPI == SAM_EPI_DGELU) {
+        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];
+        v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
+        v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
+      }
+      if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+        if (p.thr16) {
+          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+          const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
+          v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
+          v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
+          v[2] = (hi & 0xffffu) >= p.thr16 ? v[2] * p.inv_keep : 0.f;
+          v[3] = (hi >> 16) >= p.thr16 ? v[3] * p.inv_keep : 0.f;
+        }
+        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];   // zeros when there is no residual
+        v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
+      }
+      if (FULL || (m < p.M && n < p.N)) Store4<OutT>::st(Cout, (int64_t)m * ldc + n, v, F32_OUT ? 0 : accumulate);
+    }
+  }
+}
+template <int TM, int TN, int EPI, typename OutT, int T0 = 0, int T1 = TM>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, bool full, void* Cout, int64_t ldc, int accumulate, int i, int g) {
+  if (full) gemm_epilogue_impl<TM, TN, EPI, OutT, true, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
+  else gemm_epilogue_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
+}
+
+// ---- 8-wide epilogue (8-wave kernels).  A row-per-lane epilogue that stores 8 bytes per lane writes 32-byte row segments and is bound by
+// store ISSUE, not bandwidth (a 192x192 bf16 tile took ~6 us to leave through 18 dwordx2 stores per lane: a third of a 12-k-tile tile).
+// v_permlane16_swap exchanges the odd 16-lane rows of one register with the even rows of another: applied to the accumulators of the column
+// fragment pair (tn, tn+1), lane (i, g) ends up with EIGHT consecutive columns n = nw + 16 tn + 16 (g & 1) + 8 (g >> 1) .. +7 of row
+// m = mw + 16 tm + i.  Everything downstream is then 16 bytes wide: residual / pre-activation loads, one Philox call per 8 outputs (the
+// (row, col/8) stream of the 4-wide epilogue, which computed it twice), and dwordx4 stores covering 64 contiguous bytes per row.
+// An odd last column fragment goes through the 4-wide code.
+template <int TM, int TN, int EPI, typename OutT, bool FULL, int T0, int T1>
+__device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, void* Cout, int64_t ldc, int accumulate, int i, int g) {
+  constexpr int NP = TN / 2;
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  const int n_last = max(p.N - 8, 0), m_last = p.M - 1;
+  const int ncol = nw + 16 * (g & 1) + 8 * (g >> 1);
+  float4 b4[NP][2];
+  uint4 pre[HAS_PRE ? T1 - T0 : 1][HAS_PRE ? NP : 1];
+  if (HAS_BIAS) {
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      b4[q][0] = b4[q][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) {
+        const float* bp = p.bias + (FULL ? ncol + 32 * q : min(ncol + 32 * q, n_last));
+        b4[q][0] = *reinterpret_cast<const float4*>(bp);
+        b4[q][1] = *reinterpret_cast<const float4*>(bp + 4);
+      }
+    }
+  }
+  if (HAS_PRE) {
+    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
+    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
+#pragma unroll
+    for (int tm = T0; tm < T1; ++tm)
+#pragma unroll
+      for (int q = 0; q < NP; ++q) pre[tm - T0][q] = make_uint4(0u, 0u, 0u, 0u);
+    if (src)
+#pragma unroll
+      for (int tm = T0; tm < T1; ++tm)
+#pragma unroll
+        for (int q = 0; q < NP; ++q)
+          pre[tm - T0][q] = *reinterpret_cast<const uint4*>(src + (int64_t)(FULL ? mw + tm * 16 + i : min(mw + tm * 16 + i, m_last)) * lds_ +
+                                                            (FULL ? ncol + 32 * q : min(ncol + 32 * q, n_last)));
+  }
+#pragma unroll
+  for (int tm = T0; tm < T1; ++tm) {
+    const int m = mw + tm * 16 + i;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const int n = ncol + 32 * q;
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(acc[2 * q][tm][r]), __float_as_uint(acc[2 * q + 1][tm][r]), false, false);
+        v[r] = __uint_as_float(sw[0]);
+        v[4 + r] = __uint_as_float(sw[1]);
+      }
+      const bool ok = FULL || (m < p.M && n < p.N);
+      if (sizeof(OutT) == 4 && accumulate) {
+        if (ok) {
+          const float4 c0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cout) + (int64_t)m * ldc + n);
+          const float4 c1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(Cout) + (int64_t)m * ldc + n + 4);
+          v[0] += c0.x; v[1] += c0.y; v[2] += c0.z; v[3] += c0.w; v[4] += c1.x; v[5] += c1.y; v[6] += c1.z; v[7] += c1.w;
+        }
+      }
+      if (HAS_BIAS) {
+        v[0] += b4[q][0].x; v[1] += b4[q][0].y; v[2] += b4[q][0].z; v[3] += b4[q][0].w;
+        v[4] += b4[q][1].x; v[5] += b4[q][1].y; v[6] += b4[q][1].z; v[7] += b4[q][1].w;
+      }
+      if (EPI == SAM_EPI_BIAS_GELU) {
+        if (ok)
+          *reinterpret_cast<uint4*>(p.aux_out + (int64_t)m * p.ld_aux + n) =
+              make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
+      }
+      if (EPI == SAM_EPI_DGELU) {
+        const uint4 x = pre[HAS_PRE ? tm - T0 : 0][HAS_PRE ? q : 0];
+        v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x)); v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
+        v[4] *= gelu_erf_grad(bf_lo(x.z)); v[5] *= gelu_erf_grad(bf_hi(x.z)); v[6] *= gelu_erf_grad(bf_lo(x.w)); v[7] *= gelu_erf_grad(bf_hi(x.w));
+      }
+      if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+        if (p.thr16) {
+          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+          const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[2 * r] = (w4[r] & 0xffffu) >= p.thr16 ? v[2 * r] * p.inv_keep : 0.f;
+            v[2 * r + 1] = (w4[r] >> 16) >= p.thr16 ? v[2 * r + 1] * p.inv_keep : 0.f;
+          }
+        }
+        const uint4 x = pre[HAS_PRE ? tm - T0 : 0][HAS_PRE ? q : 0];   // zeros when there is no residual
+        v[0] += bf_lo(x.x); v[1] += bf_hi(x.x); v[2] += bf_lo(x.y); v[3] += bf_hi(x.y);
+        v[4] += bf_lo(x.z); v[5] += bf_hi(x.z); v[6] += bf_lo(x.w); v[7] += bf_hi(x.w);
+      }
+      if (ok) {
+        if (sizeof(OutT) == 4) {
+          float* dst = reinterpret_cast<float*>(Cout) + (int64_t)m * ldc + n;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cout) + (int64_t)m * ldc + n) =
+              make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+        }
+      }
+    }
+  }
+  if constexpr (TN % 2 == 1) gemm_epilogue_impl<TM, TN, EPI, OutT, FULL, T0, T1, TN - 1, TN>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
+}
+template <int TM, int TN, int EPI, typename OutT, int T0 = 0, int T1 = TM>
+__device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, bool full, void* Cout, int64_t ldc, int accumulate, int i, int g) {
+  if (full) gemm_epilogue8_impl<TM, TN, EPI, OutT, true, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
+  else gemm_epilogue8_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
+}
+
+// 8-wave persistent kernels (gemm8.hip).  tile: 0 = heuristic, 1192 / 1256 = force the 192x192 / 256x256 configuration.
+// Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
+// has no instance there: the caller then uses the 4-wave kernels.
+int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
+
+}  // namespace samgemm

@@ -178,6 +178,54 @@ def test_both_tile_configs_all_layouts(tile):
     assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
 
 
+@pytest.mark.parametrize("tile", [1192, 1256])
+@pytest.mark.parametrize("M,N,K", [(3500, 3080, 128), (600, 520, 64), (4000, 2304, 192), (256, 256, 704)])
+def test_eight_wave_persistent_kernels(tile, M, N, K):
+    """gemm8.hip (256x256 / 192x192 tiles, one block per CU walking several tiles): ragged M and N, one to eleven k-tiles per tile, more tiles
+    than CUs (so blocks cross tile boundaries with operands of the next tile in flight), forward and dgrad layouts, every fused epilogue"""
+    ops, capi = _mods()
+    x, w = rnd((M, K), 61), rnd((N, K), 62, 0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(63)) * 0.1
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    ref = x.float() @ w.float().t()
+    assert_close_bf16(ops.gemm(xg, wg, force_tile=tile), ref, name="fwd none")
+    assert_close_bf16(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ref + b, name="fwd bias")
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    h = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_GELU, bias=bg, aux_out=pre, force_tile=tile)
+    assert_close_bf16(pre, ref + b, name="fwd pre-gelu")
+    assert_close_bf16(h, gelu(ref + b), name="fwd gelu")
+    res = rnd((M, N), 64)
+    z = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), force_tile=tile)
+    assert_close_bf16(z, ref + b + res.float(), name="fwd bias+res")
+    # dropout: the same Philox (row, col/8) stream as the 4-wave kernels -> identical keep pattern, values equal up to the accumulation order
+    zd = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), p_drop=0.1, seed=11, offset=3, force_tile=tile)
+    z4 = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), p_drop=0.1, seed=11, offset=3, force_tile=128)
+    assert_close_bf16(zd, z4.float(), ulps=2, name="fwd dropout+res vs 4-wave kernel")
+    # dgrad layout: dy[M,K] . W[K,N]
+    wT = rnd((K, N), 65, 0.05)
+    refd = x.float() @ wT.float()
+    assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, force_tile=tile), refd, name="dgrad none")
+    prev = rnd((M, N), 66)
+    xp = prev.float()
+    dg = 0.5 * (1 + torch.erf(xp / math.sqrt(2))) + xp * torch.exp(-0.5 * xp * xp) / math.sqrt(2 * math.pi)
+    assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=prev.cuda(), force_tile=tile), refd * dg, name="dgrad dgelu")
+    assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=res.cuda(), force_tile=tile), refd + res.float(), name="dgrad+res")
+    # strided operand views (leading dimensions larger than the logical width), as the attention block hands them over
+    big = rnd((M, K + 64), 67).cuda()
+    assert_close_bf16(ops.gemm(big[:, 64:], wg, force_tile=tile), big[:, 64:].float().cpu() @ w.float().t(), name="lda view")
+    # bit-reproducible
+    assert torch.equal(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile))
+
+
+def test_eight_wave_kernels_decline_what_they_cannot_do():
+    ops, capi = _mods()
+    x, w = rnd((512, 72), 71).cuda(), rnd((512, 72), 72).cuda()
+    with pytest.raises(capi.SamHipError):
+        ops.gemm(x, w, force_tile=1192)              # K % 64 != 0: no partial k-tiles there
+    y = ops.gemm(x, w)                               # the heuristic path falls back to the 4-wave kernels
+    assert_close_bf16(y, x.float().cpu() @ w.float().cpu().t(), name="fallback")
+
+
 def test_grouped_wgrad_matches_individual():
     ops, capi = _mods()
     R = 1456
