@@ -22,6 +22,8 @@ extern "C" {
 #define SAM_ERR_UNSUPPORTED (-2)
 
 int sam_abi_version(void);
+/* sha256 of the sources + compile flags this binary was built from (the Python binding refuses a library whose digest differs from the tree's) */
+const char* sam_build_digest(void);
 const char* sam_last_error(void);
 int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len);
 
@@ -128,10 +130,12 @@ int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* out, int ac
 /* ---- M4CDecodingBCEWithMaskLoss, sam/task_utils.py:19-30: forward value AND analytic gradient in one pass ----
  * scores arrive as the two blocks the model produces (classifier logits [R,V] and pointer scores [R,No], both fp32,
  * R = B*S decoding rows); loss = sum(bce * mask[r]) / max(sum(mask),1); d_fixed bf16 [R,V], d_ocr fp32 [R,No], both
- * already multiplied by grad_scale (1/world for data-parallel averaging). */
+ * already multiplied by grad_scale.  global_count (device scalar, may be NULL): data-parallel runs pass the all-reduced number of unmasked
+ * decoding steps of the GLOBAL batch; the normaliser is then max(global_count, 1) as under the reference's nn.DataParallel (train.py:111-112
+ * gathers the scores before the loss), so the SUM of the ranks' losses / gradients is the global-batch loss / gradient. */
 int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, const float* targets, int64_t ld_t,
-                 const float* loss_mask, int R, int V, int No, float grad_scale, float* loss, void* d_fixed, int64_t ld_dfixed, float* d_ocr,
-                 int64_t ld_docr, void* stream);
+                 const float* loss_mask, int R, int V, int No, float grad_scale, const float* global_count, float* loss, void* d_fixed,
+                 int64_t ld_dfixed, float* d_ocr, int64_t ld_docr, void* stream);
 
 /* ---- OcrPtrNet bilinear scores, sam/sa_m4c.py:891-893: out[b,s,o] = scale*<q[b,s],k[b,o]> + (1-mask[b,o])*-10000 ----
  * q bf16 [B,S,D], k bf16 [B,No,D] (already projected), mask u8 [B,No]; out fp32 with element strides (ld_out_b, ld_out_s) */
@@ -144,6 +148,10 @@ int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const v
  * dy bf16 [T,D]; idx int64 [T]; grad fp32 [rows, ldg]; rows outside [0,rows) and row == padding_idx (nn.Embedding semantics; -1 = none)
  * are skipped.  fp32 atomics (rows may repeat). */
 int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream);
+/* the same sum in a FIXED order for an index list sorted ascending (one writer per table row, no atomics): what the data-parallel row-sparse
+ * exchange uses, so that every rank adds up bit-identical gradients from the same gathered list */
+int sam_embedding_bwd_sorted(const void* dy, int64_t ldd, const int64_t* idx_sorted, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
+                             void* stream);
 
 /* ---- front end: feature normalisation + packing, embedding sums, previous-prediction gather (csrc/embed.hip) ----
  * sam_l2norm_pack_bf16: F.normalize(x, dim=-1) (x / max(||x||_2, eps); normalize = 0: plain cast) of fp32 rows [M, D], rounded to bf16 and

@@ -32,25 +32,54 @@ def _digest():
     return h.hexdigest()
 
 
+def _headers_digest():
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith(".h"):
+            h.update(f.encode())
+            h.update(open(os.path.join(CSRC, f), "rb").read())
+    inc = os.path.join(os.path.dirname(PKG), "include", "sam_hip.h")
+    if os.path.exists(inc):
+        h.update(open(inc, "rb").read())
+    return h
+
+
 def build(force=False, verbose=False):
+    """compile what changed (per-object stamps: source + every header + flags), link, stamp the library with the digest of the whole tree.
+    Any compile or link error raises: a stale library is never left in place as if it were current."""
     os.makedirs(LIB_DIR, exist_ok=True)
     stamp = os.path.join(LIB_DIR, "libsam_hip.sha256")
     dig = _digest()
     if not force and os.path.exists(LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
         return LIB
-    objs = []
-    procs = []
+    hdr = _headers_digest()
+    objs, procs = [], []
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-I", os.path.join(os.path.dirname(PKG), "include"), "-c", src, "-o", obj]
+        is_runtime = os.path.basename(src) == "runtime.cpp"
+        h = hdr.copy()
+        h.update(open(src, "rb").read())
+        if is_runtime:
+            h.update(dig.encode())                # carries the digest string of the whole tree
+        odig, ostamp = h.hexdigest(), obj + ".sha256"
+        if not force and os.path.exists(obj) and os.path.exists(ostamp) and open(ostamp).read().strip() == odig:
+            continue
+        cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + (['-DSAM_BUILD_DIGEST="%s"' % dig] if is_runtime else []) + \
+              ["-I", os.path.join(os.path.dirname(PKG), "include"), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for src, p in procs:
+        if os.path.exists(ostamp):
+            os.remove(ostamp)
+        procs.append((src, ostamp, odig, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, ostamp, odig, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError("hipcc failed on %s:\n%s" % (src, out.decode(errors="replace")))
+        with open(ostamp, "w") as f:
+            f.write(odig)
+    if os.path.exists(stamp):
+        os.remove(stamp)
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:

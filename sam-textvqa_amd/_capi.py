@@ -44,10 +44,11 @@ SIGNATURES = {
     "sam_layernorm_bwd_ws_bytes": [_i],
     "sam_colsum_ws_bytes": [_i],
     "sam_colsum_bf16": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp],
-    "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _i64, _vp, _i64, _vp],
+    "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     "sam_ptr_scores_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i64, _i64, _vp],
     "sam_ptr_scores_bwd": [_vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
     "sam_embedding_bwd": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
+    "sam_embedding_bwd_sorted": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
     "sam_l2norm_pack_bf16": [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _i, _vp],
     "sam_embed_sum_fwd": [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _vp],
     "sam_embed_sum_bwd_ws_bytes": [_i, _i, _i],
@@ -77,16 +78,16 @@ def lib():
             if not os.path.exists(alt):
                 raise SamHipError("SAM_HIP_LIB=%s does not exist" % alt)
             LIB_PATH = alt
-        # (re)build when the sources changed or the library is missing; a no-op (source hash compare) otherwise.  If that is
-        # impossible (no hipcc) and no library exists, fail: there is no fallback path.
-        try:
+        # (re)build when the sources changed or the library is missing; a no-op (digest compare) otherwise.  A failed build raises: an older
+        # libsam_hip.so is never loaded in place of the sources in the tree (changed signatures against an old binary = silent corruption).
+        want = None
+        if not alt:
             from . import _build
-            if not alt:
+            try:
                 _build.build()
-        except Exception as e:
-            if not os.path.exists(LIB_PATH):
-                raise SamHipError("libsam_hip.so is missing and could not be built (%s): run `python __graft_entry__.py`; "
-                                  "there is no fallback path" % e)
+            except Exception as e:
+                raise SamHipError("libsam_hip.so could not be (re)built from the sources in the tree (%s); there is no fallback path" % e)
+            want = _build._digest()
         if not os.path.exists(LIB_PATH):
             raise SamHipError("libsam_hip.so not built (%s): run `python __graft_entry__.py` or "
                               "sam_textvqa_amd._build.build(); there is no fallback path" % LIB_PATH)
@@ -98,6 +99,10 @@ def lib():
             C.CDLL(hip_rt, mode=C.RTLD_GLOBAL)
         l = C.CDLL(LIB_PATH)
         l.sam_last_error.restype = C.c_char_p
+        l.sam_build_digest.restype = C.c_char_p
+        have = l.sam_build_digest().decode()
+        if want is not None and have != want:
+            raise SamHipError("libsam_hip.so was built from other sources (digest %s..., tree %s...): rebuild with `python __graft_entry__.py`" % (have[:12], want[:12]))
         for name, args in SIGNATURES.items():
             fn = getattr(l, name)
             fn.argtypes = args

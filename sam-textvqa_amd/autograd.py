@@ -17,7 +17,7 @@ BF16 = torch.bfloat16
 
 class DropoutClock:
     """Philox (seed, offset) source: every dropout site of every step gets a fresh offset; forward and backward of
-    one site share it.  Seed is per rank so data-parallel replicas draw different masks."""
+    one site share it.  The Trainer folds the rank into the seed (seed ^ rank << 32) so data-parallel replicas draw different masks."""
 
     def __init__(self):
         self.seed = 0x5A4D3443  # "SAM4C"
@@ -383,14 +383,12 @@ class BceLossFn(Function):
     """M4CDecodingBCEWithMaskLoss (sam/task_utils.py:19-30) on the two score blocks; gradient computed in the forward pass"""
 
     @staticmethod
-    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale, unit_grad=False, count_ratio=None):
+    def forward(ctx, fixed, ocr, targets, loss_mask, grad_scale, unit_grad=False, global_count=None):
         r = fixed.shape[0] * fixed.shape[1]
         f2, o2 = fixed.reshape(r, -1), ocr.reshape(r, -1)
-        loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale)
-        if count_ratio is not None:          # data parallel: this rank's share of the global normaliser (device scalar, no host sync)
-            d_fixed.mul_(count_ratio.to(BF16))
-            d_ocr.mul_(count_ratio)
-            loss = loss * count_ratio
+        # data parallel: global_count = all-reduced number of unmasked decoding steps (device scalar, no host sync); the kernel normalises
+        # by max(global_count, 1) in fp32, so loss and both gradient blocks carry exactly this rank's share of the global mean
+        loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale, global_count)
         ctx.save_for_backward(d_fixed, d_ocr)
         ctx.shapes, ctx.unit_grad = (fixed.shape, ocr.shape), unit_grad
         return loss[0]

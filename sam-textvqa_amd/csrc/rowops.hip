@@ -257,8 +257,8 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* x, in
 // ------------------------------------------------------------------------------------------ BCE loss
 // loss = sum_{r,c} bce(x, t) * mask[r] / max(sum(mask), 1);  d x = (sigmoid(x) - t) * mask[r] * gscale / count
 __global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ldf, const float* ocr, int64_t ldoc, const float* targets, int64_t ldt,
-                                                  const float* mask, int R, int V, int No, float gscale, float* loss, bf16_t* d_fixed, int64_t lddf,
-                                                  float* d_ocr, int64_t lddo) {
+                                                  const float* mask, int R, int V, int No, float gscale, const float* global_count, float* loss,
+                                                  bf16_t* d_fixed, int64_t lddf, float* d_ocr, int64_t lddo) {
   __shared__ float sred[4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float cnt = 0.f;
@@ -266,7 +266,9 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ld
   cnt = wave_sum(cnt);
   if (lane == 0) sred[wave] = cnt;
   __syncthreads();
-  cnt = fmaxf(sred[0] + sred[1] + sred[2] + sred[3], 1.0f);
+  // data parallel: the normaliser is the number of unmasked decoding steps of the GLOBAL batch (all-reduced by the caller, raw: the
+  // clamp is applied to the global value as the reference does, task_utils.py:28-29); every rank then contributes sum_local / max(C, 1)
+  cnt = fmaxf(global_count ? global_count[0] : sred[0] + sred[1] + sred[2] + sred[3], 1.0f);
   __syncthreads();
   const float inv_cnt = 1.0f / cnt;
   const int W = V + No;
@@ -414,6 +416,28 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, in
   }
 }
 
+// deterministic variant: idx sorted ascending; the block of the FIRST occurrence of a row walks all its duplicates in order and is the
+// only writer of that table row (data parallel: every rank scatters the same gathered list and must end with bit-identical gradients)
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg) {
+  const int t = blockIdx.x;
+  const int64_t row = idx[t];
+  if (row < 0 || row >= rows || row == padding_idx || (t > 0 && idx[t - 1] == row)) return;
+  int end = t + 1;
+  while (end < T && idx[end] == row) ++end;
+  for (int c = threadIdx.x; c * 4 < D; c += 256) {
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s = t; s < end; ++s) {
+      float v[4];
+      Ld4<bf16_t>::ld(dy, (int64_t)s * ldd + 4 * c, v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += v[e];
+    }
+    float4* g = reinterpret_cast<float4*>(grad + row * ldg + 4 * c);
+    const float4 o = *g;
+    *g = make_float4(o.x + a[0], o.y + a[1], o.z + a[2], o.w + a[3]);
+  }
+}
+
 template <typename InT>
 int ln_fwd_dispatch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D,
                     void* y, int64_t ldy, float* mean, float* rstd) {
@@ -487,8 +511,8 @@ extern "C" int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* 
 }
 
 extern "C" int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, const float* targets, int64_t ld_t,
-                            const float* loss_mask, int R, int V, int No, float grad_scale, float* loss, void* d_fixed, int64_t ld_dfixed, float* d_ocr,
-                            int64_t ld_docr, void* stream) {
+                            const float* loss_mask, int R, int V, int No, float grad_scale, const float* global_count, float* loss, void* d_fixed,
+                            int64_t ld_dfixed, float* d_ocr, int64_t ld_docr, void* stream) {
   SAM_REQUIRE(fixed_scores && ocr_scores && targets && loss_mask && loss && d_fixed && d_ocr, "sam_bce_loss: null pointer");
   SAM_REQUIRE(R > 0 && V > 0 && No >= 0, "sam_bce_loss: bad shape");
   hipStream_t st = (hipStream_t)stream;
@@ -496,7 +520,7 @@ extern "C" int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const f
   if (e != hipSuccess) { sam_set_error("sam_bce_loss: memset: %s", hipGetErrorString(e)); return (int)e; }
   const int64_t total = (int64_t)R * (V + No);
   const int blocks = (int)min((int64_t)2048, (total + 255) / 256);
-  bce_kernel<<<dim3(blocks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, loss,
+  bce_kernel<<<dim3(blocks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, global_count, loss,
                                                  (bf16_t*)d_fixed, ld_dfixed, d_ocr, ld_docr);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
@@ -524,6 +548,15 @@ extern "C" int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx
   SAM_REQUIRE(dy && idx && grad, "sam_embedding_bwd: null pointer");
   SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && rows > 0, "sam_embedding_bwd: bad shape");
   embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_embedding_bwd_sorted(const void* dy, int64_t ldd, const int64_t* idx_sorted, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
+                                       void* stream) {
+  SAM_REQUIRE(dy && idx_sorted && grad, "sam_embedding_bwd_sorted: null pointer");
+  SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && ldg % 4 == 0 && rows > 0 && ((uintptr_t)grad % 16 == 0), "sam_embedding_bwd_sorted: bad shape");
+  embedding_bwd_sorted_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx_sorted, T, D, rows, padding_idx, grad, ldg);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -12,7 +12,11 @@ extern "C" void sam_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* sam_last_error(void) { return g_err; }
-extern "C" int sam_abi_version(void) { return 1; }
+extern "C" int sam_abi_version(void) { return 2; }    // 2: sam_bce_loss takes global_count; sam_embedding_bwd_sorted; sam_build_digest; sam_gemm_desc.force_tile 1192/1256
+#ifndef SAM_BUILD_DIGEST
+#define SAM_BUILD_DIGEST "unknown"
+#endif
+extern "C" const char* sam_build_digest(void) { return SAM_BUILD_DIGEST; }
 
 extern "C" int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len) {
   hipDeviceProp_t p;

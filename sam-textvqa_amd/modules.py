@@ -6,7 +6,9 @@ task_utils.py:118; evaluator.py:168) can switch imports.  All arithmetic runs in
 libsam_hip.so through autograd.py; there is no eager fallback: the modules raise if the library is missing or
 the tensors are not on the GPU.  Activations are bf16 between kernels, parameters are fp32 masters with bf16
 shadows (params.py)."""
+import logging
 import math
+import os
 from collections import Counter
 
 import torch
@@ -412,8 +414,7 @@ class BertSpatialEncoder(_HipModule):
             if kind == "n":
                 hidden_states = next(normal)(hidden_states, allow)[0]
             elif kind == "s":
-                adj = batch_dict["spatial_adj_matrices"][self.matrix_type_map[mix]]
-                hidden_states = next(spatial)(hidden_states, allow, adj)[0]
+                hidden_states = next(spatial)(hidden_states, allow, self._adjacency_for(batch_dict, mix))[0]
             else:
                 raise ValueError   # 'i' layers are rejected by the reference as well (sa_m4c.py:751-752)
         assert next(normal, None) is None and next(spatial, None) is None
@@ -421,6 +422,15 @@ class BertSpatialEncoder(_HipModule):
         if self.output_hidden_states:
             outputs += (all_hidden + (hidden_states,),)
         return outputs
+
+    def _adjacency_for(self, batch_dict, mix):
+        """relation tensor of spatial context `mix` (sa_m4c.py:746-747)"""
+        key = self.matrix_type_map[mix]
+        mats = batch_dict["spatial_adj_matrices"]
+        if key not in mats:
+            raise KeyError("SA-M4C.mix_list asks for %r heads (relation tensor %r) but the batch only carries contexts %s: the dataset-level "
+                           "mix_list and the model's mix_list disagree (as in the shipped train-tvqa-eval-tvqa-c5.yml)" % (mix, key, sorted(mats)))
+        return mats[key]
 
     def _layer_plan(self, allow, batch_dict, n_txt):
         """[(layer, allow bits)] in execution order"""
@@ -430,8 +440,7 @@ class BertSpatialEncoder(_HipModule):
                 plan.append((next(normal), allow.base))
             elif kind == "s":
                 layer = next(spatial)
-                adj = batch_dict["spatial_adj_matrices"][self.matrix_type_map[mix]]
-                plan.append((layer, layer.attention.self._allow_bits(allow, adj)))
+                plan.append((layer, layer.attention.self._allow_bits(allow, self._adjacency_for(batch_dict, mix))))
             else:
                 raise ValueError
         return plan
@@ -562,6 +571,31 @@ def _pack_features(parts, normalize, n_zero_cols):
     return out.view(b, n, k_pad)
 
 
+def load_bert_base_into(text_bert, path):
+    """copy the embeddings and the first num_hidden_layers encoder layers of a bert-base-uncased state dict into `text_bert`
+    (what TextBert.from_pretrained("bert-base-uncased", config=...) does upstream, sa_m4c.py:76-78, minus the download)"""
+    if os.path.isdir(path):
+        cands = [os.path.join(path, f) for f in ("model.safetensors", "pytorch_model.bin")]
+        path = next((c for c in cands if os.path.exists(c)), cands[-1])
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        sd = load_file(path)
+    else:
+        sd = torch.load(path, map_location="cpu", weights_only=True)
+    own = text_bert.state_dict()
+    got = {}
+    for k, v in sd.items():
+        k = k[5:] if k.startswith("bert.") else k
+        k = k.replace("LayerNorm.gamma", "LayerNorm.weight").replace("LayerNorm.beta", "LayerNorm.bias")
+        if k in own and own[k].shape == v.shape:
+            got[k] = v
+    missing = [k for k in own if k not in got]
+    if missing:
+        raise RuntimeError("bert-base weights at %s lack %d TextBert tensors (first: %s)" % (path, len(missing), missing[0]))
+    text_bert.load_state_dict(got, strict=True)
+    return text_bert
+
+
 class SAM4C(_HipModule):
     """sam/sa_m4c.py:20-371 (aux heads, beam search and the fc7-finetune image encoder are out of scope: disabled /
     dead upstream)."""
@@ -574,9 +608,19 @@ class SAM4C(_HipModule):
             raise NotImplementedError("use_aux_heads is absent from every shipped config; not implemented")
         self.finetune_modules = []
         h = mmt_config.hidden_size
-        if text_bert_config.text_bert_init_from_bert_base:
-            raise NotImplementedError("text_bert_init_from_bert_base needs a network download; load a checkpoint instead")
         self.text_bert = TextBert(text_bert_config)
+        if getattr(text_bert_config, "text_bert_init_from_bert_base", False):
+            # sa_m4c.py:74-85: TextBert starts from bert-base-uncased and trains at lr_scale_text_bert x the base rate (its own optimizer group,
+            # BEFORE the MMT group).  The reference downloads the weights; here they come from a local file / directory
+            # (config key `text_bert_pretrained_path` or $SAM_BERT_BASE: a state dict with `bert.embeddings.*` / `bert.encoder.layer.N.*`
+            # keys, .bin / .pt / .safetensors), or later from a checkpoint -- without one the layers keep their N(0, 0.02) init.
+            src = getattr(text_bert_config, "text_bert_pretrained_path", None) or os.environ.get("SAM_BERT_BASE")
+            if src:
+                load_bert_base_into(self.text_bert, src)
+            else:
+                logging.getLogger(__name__).warning("text_bert_init_from_bert_base: no local bert-base-uncased weights given "
+                                                    "(text_bert_pretrained_path / $SAM_BERT_BASE); TextBert keeps its random init until a checkpoint is loaded")
+            self.finetune_modules.append({"module": self.text_bert, "lr_scale": getattr(text_bert_config, "lr_scale_text_bert", 1.0)})
         self.text_bert_out_linear = nn.Identity() if h == 768 else nn.Linear(768, h)
         self.linear_obj_feat_to_mmt_in = nn.Linear(mmt_config.obj_feature_size, h)
         self.linear_obj_bbox_to_mmt_in = nn.Linear(4, h)

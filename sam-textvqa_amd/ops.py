@@ -269,15 +269,16 @@ def gather2_add_bwd(dy, inds, v, n_ocr, want_emb=True, p_drop=0.0, seed=0, offse
 
 
 # ----------------------------------------------------------------------------- loss / pointer net / optimizer
-def bce_loss(fixed, ocr, targets, loss_mask, grad_scale=1.0):
-    """fixed f32 [R,V], ocr f32 [R,No], targets f32 [R,V+No], loss_mask f32 [R] -> (loss f32 [1], d_fixed bf16 [R,V], d_ocr f32 [R,No])"""
+def bce_loss(fixed, ocr, targets, loss_mask, grad_scale=1.0, global_count=None):
+    """fixed f32 [R,V], ocr f32 [R,No], targets f32 [R,V+No], loss_mask f32 [R] -> (loss f32 [1], d_fixed bf16 [R,V], d_ocr f32 [R,No]);
+    global_count (device f32 scalar): the all-reduced number of unmasked steps of the global batch, used as the normaliser instead of this rank's"""
     r, v = fixed.shape
     no = ocr.shape[1]
     loss = torch.empty(1, dtype=torch.float32, device=fixed.device)
     d_fixed = torch.empty((r, v), dtype=BF16, device=fixed.device)
     d_ocr = torch.empty((r, no), dtype=torch.float32, device=fixed.device)
     capi.call("sam_bce_loss", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), capi.ptr(targets), targets.stride(0), capi.ptr(loss_mask),
-              r, v, no, float(grad_scale), capi.ptr(loss), capi.ptr(d_fixed), d_fixed.stride(0), capi.ptr(d_ocr), d_ocr.stride(0), capi.stream_handle())
+              r, v, no, float(grad_scale), capi.ptr(global_count), capi.ptr(loss), capi.ptr(d_fixed), d_fixed.stride(0), capi.ptr(d_ocr), d_ocr.stride(0), capi.stream_handle())
     return loss, d_fixed, d_ocr
 
 
@@ -325,6 +326,13 @@ def embedding_bwd(dy, idx, grad_table, padding_idx=-1):
     t, d = dy.shape
     capi.call("sam_embedding_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(idx), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table), grad_table.stride(0),
               capi.stream_handle())
+
+
+def embedding_bwd_sorted(dy, idx_sorted, grad_table, padding_idx=-1):
+    """embedding_bwd for an index list sorted ascending: fixed summation order, one writer per table row (no atomics)"""
+    t, d = dy.shape
+    capi.call("sam_embedding_bwd_sorted", capi.ptr(dy), dy.stride(0), capi.ptr(idx_sorted), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table),
+              grad_table.stride(0), capi.stream_handle())
 
 
 def mask_bits_from_int8_bhnn(rel, base_bits=None):

@@ -22,10 +22,15 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0, scatter_fn=None):
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0, scatter_fn=None, sparse_range=None):
         self.grad = flat_grad
         self.scatter_fn = scatter_fn or _scatter_rows
-        self.dense_lo = int(dense_lo)     # [0, dense_lo) is exchanged through sparse_rows(), not all-reduced
+        # [sparse_lo, sparse_hi) is exchanged through sparse_rows(), not all-reduced.  `dense_lo=k` is the short form of sparse_range=(0, k)
+        # (two optimizer groups: the word-embedding table is the first parameter of flat storage); with the reference's three groups
+        # (text_bert_init_from_bert_base) the table sits in the middle of the buffer, in front of the rest of TextBert.
+        self.sparse_lo, self.sparse_hi = (0, int(dense_lo)) if sparse_range is None else (int(sparse_range[0]), int(sparse_range[1]))
+        self.dense_lo = self.sparse_hi if self.sparse_lo == 0 else 0
+        self._checked_rows = False
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         # SAM_FORCE_DIST=1: run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
@@ -38,16 +43,19 @@ class GradReducer:
         self.overlap = overlap and flat_grad.is_cuda and (self.world_size > 1 or self.force)
         self.stream = torch.cuda.Stream() if self.overlap else None
         self.regions = []
-        self.barrier_names, self.barrier_region = set(), None
+        self.barrier_names, self.barrier_regions = set(), []
         self.begin_step()
 
     def _build_buckets(self, cut):
-        """buckets walk the dense range [dense_lo, n) from the end (ascending index = descending addresses = backward order).  `cut`: a
-        forced boundary (the low end of the registered regions): a bucket straddling it would mix gradients that are final early (encoder
-        layers) with ones that are final last (everything below) and could only leave at finish()."""
+        """buckets walk the dense ranges [sparse_hi, n) and [0, sparse_lo) from the end (ascending index = descending addresses = backward
+        order).  `cut`: a forced boundary (the low end of the registered regions): a bucket straddling it would mix gradients that are final
+        early (encoder layers) with ones that are final last (everything below) and could only leave at finish()."""
         n, per = self.grad.numel(), self.per_bucket
+        edges = sorted({0, n, self.sparse_lo, self.sparse_hi} | ({cut} if cut is not None and 0 < cut < n else set()), reverse=True)
         self.buckets = []
-        for top, bottom in ((n, cut), (cut, self.dense_lo)) if cut is not None and self.dense_lo < cut < n else ((n, self.dense_lo),):
+        for top, bottom in zip(edges[:-1], edges[1:]):
+            if bottom >= self.sparse_lo and top <= self.sparse_hi:
+                continue                                   # the row-sparse table
             hi = top
             while hi > bottom:
                 lo = max(bottom, hi - per)
@@ -60,7 +68,7 @@ class GradReducer:
         order = sorted(range(len(ranges)), key=lambda i: -ranges[i][0])
         self.regions = [ranges[i] for i in order]
         for (lo_hi, above) in zip(self.regions[1:], self.regions[:-1]):
-            if lo_hi[1] != above[0]:
+            if lo_hi[1] != above[0] and not (lo_hi[1] == self.sparse_lo and above[0] == self.sparse_hi):      # (the sparse table may sit between two regions)
                 raise ValueError("gradient regions must tile a contiguous range up to the end of the buffer: gap between %r and %r" % (lo_hi, above))
         if self.regions and self.regions[0][1] != self.grad.numel():
             raise ValueError("the highest gradient region must end at the end of the flat buffer")
@@ -86,17 +94,25 @@ class GradReducer:
         if self.done_ptr > 0:
             self.region_done(self.regions[self.done_ptr - 1][0])
 
-    def set_barrier(self, names, region_id):
-        """region `region_id` is final once every name in `names` has been reported by barrier_hit (autograd.GradBarrierFn)"""
-        self.barrier_names, self.barrier_region = set(names), region_id
+    def set_barrier(self, names, region_ids):
+        """the regions `region_ids` (one id or a list) are final once every name in `names` has been reported by barrier_hit
+        (autograd.GradBarrierFn)"""
+        self.barrier_names = set(names)
+        self.barrier_regions = [region_ids] if isinstance(region_ids, int) else list(region_ids)
+
+    @property
+    def barrier_region(self):
+        return self.barrier_regions[0] if self.barrier_regions else None
 
     def barrier_hit(self, name):
-        if self.barrier_region is None:
+        if not self.barrier_regions:
             return
         self._note_stream()
         self.barrier_seen.add(name)
-        if self.barrier_names <= self.barrier_seen and not self.done[self.barrier_region]:
-            self.mark_done(self.barrier_region)
+        if self.barrier_names <= self.barrier_seen:
+            for rid in self.barrier_regions:
+                if not self.done[rid]:
+                    self.mark_done(rid)
 
     def begin_step(self):
         self.grad_streams = [torch.cuda.current_stream()] if self.grad.is_cuda else []
@@ -141,6 +157,12 @@ class GradReducer:
         the data-parallel exchange of a row-sparse gradient living in [0, dense_lo)."""
         if self.world_size > 1 or self.force:
             w = self.world_size
+            if not self._checked_rows:                  # all_gather_into_tensor needs the same row count on every rank: check it once, loudly
+                cnt = torch.tensor([ids.numel(), -ids.numel()], dtype=torch.int64, device=ids.device)
+                dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
+                if int(cnt[0]) != -int(cnt[1]):
+                    raise RuntimeError("GradReducer.sparse_rows: ranks hold different numbers of rows (%d..%d); pad the last batch" % (-int(cnt[1]), int(cnt[0])))
+                self._checked_rows = True
             ids_all = torch.empty((w * ids.numel(),), dtype=ids.dtype, device=ids.device)
             rows_all = torch.empty((w * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
             dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group)
@@ -166,10 +188,14 @@ class GradReducer:
 
 
 def _scatter_rows(grad_table, ids, rows, padding_idx):
-    """grad_table[ids[t], :] += rows[t, :] on the GPU (sam_embedding_bwd); there is no CPU implementation in the package -- the gloo unit
-    test of GradReducer injects its own `scatter_fn`"""
+    """grad_table[ids[t], :] += rows[t, :] on the GPU, in a FIXED order: rows are sorted by index (stable) and every table row is summed by
+    one thread block in that order (sam_embedding_bwd_sorted), so all ranks -- which hold the same gathered (index, row) list -- add up
+    bit-identical gradients and the replicas stay in lock-step (atomics would sum in an arbitrary order per rank).
+    There is no CPU implementation in the package: the gloo unit test of GradReducer injects its own `scatter_fn`."""
     from . import ops
-    ops.embedding_bwd(rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16), ids, grad_table, padding_idx)
+    order = torch.sort(ids, stable=True)
+    rows_sorted = rows.index_select(0, order.indices)
+    ops.embedding_bwd_sorted(rows_sorted if rows_sorted.dtype == torch.bfloat16 else rows_sorted.to(torch.bfloat16), order.values, grad_table, padding_idx)
 
 
 active_reducer = None   # set by the Trainer; EncoderLayerFn.backward reports finished layers to it

@@ -2,6 +2,7 @@
 forward -> masked BCE -> backward -> clip_grad_norm_(0.25) -> Adam(lr groups) -> LambdaLR warm-up/decay,
 running on the flat parameter storage so that clip + Adam + bf16 refresh are two kernels, and the
 data-parallel gradient exchange is a few large RCCL all-reduces (parallel.py)."""
+import os
 from bisect import bisect
 
 import torch
@@ -19,17 +20,18 @@ def lr_lambda(it, warmup_iters=1000, warmup_factor=0.2, lr_decay_iters=(14000, 1
     return pow(lr_decay, bisect(list(lr_decay_iters), it))
 
 
-def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, count_ratio=None):
+def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, global_count=None):
     """M4CDecodingBCEWithMaskLoss on the score blocks SAM4C.forward left in batch_dict.  unit_grad=True: the caller promises to call
     .backward() on the returned loss with the default gradient of 1 (the loss gradient is then handed on without being rescaled).
-    count_ratio: device scalar count_rank / count_global (data parallel, see Trainer.step): loss and gradient are scaled by it"""
+    global_count: device scalar, the all-reduced number of unmasked decoding steps of the global batch (data parallel, see Trainer.step)"""
     return BceLossFn.apply(batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"], batch_dict["targets"], batch_dict["train_loss_mask"], grad_scale,
-                           unit_grad, count_ratio)
+                           unit_grad, global_count)
 
 
 class Trainer:
     def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0):
         self.model = model
+        self.base_lr = base_lr
         groups = model.get_optimizer_parameters(base_lr)
         self.group_lr = [g.get("lr", base_lr) for g in groups]
         self.flat = prepare(model, groups=[g["params"] for g in groups])
@@ -41,61 +43,100 @@ class Trainer:
         self.gnorm_sq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.max_grad_norm, self.betas, self.eps = max_grad_norm, betas, eps
         self.schedule = schedule or {}
-        if reducer is None and parallel.dist.is_initialized() and (parallel.dist.get_world_size() > 1 or __import__("os").environ.get("SAM_FORCE_DIST") == "1"):
-            reducer = parallel.GradReducer(self.flat.grad, dense_lo=self._sparse_table_end())
+        dist = parallel.dist
+        if reducer is None and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SAM_FORCE_DIST") == "1"):
+            reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range())
         self.reducer = reducer
-        if reducer is not None and parallel.dist.is_initialized() and dev.type == "cuda":
-            parallel.dist.all_reduce(self.gnorm_sq)              # (zeros) creates the RCCL communicator here, not inside the first timed step
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        if reducer is not None and dist.is_initialized():
+            # replicas must START identical and nothing re-synchronises them later: rank 0's masters and optimizer state go to everyone
+            # (this also creates the RCCL communicator here, not inside the first timed step)
+            for buf in (self.flat.flat, self.exp_avg, self.exp_avg_sq):
+                dist.broadcast(buf, src=0, group=reducer.group)
+            self.flat.refresh_shadows()
         if reducer is not None:
             self._register_regions(reducer)
         self.global_step = 0
-        dropout_clock.manual_seed(seed)
+        self.epoch_id, self.current_val_score = 0, None
+        dropout_clock.manual_seed((int(seed) ^ (rank << 32)) & 0xFFFFFFFFFFFFFFFF)       # data-parallel replicas draw different masks
+
+    # ---- data-parallel layout ------------------------------------------------------------------------------
+    def _units(self):
+        """(lo, hi, trigger) for every piece of the flat buffer whose gradient is final at a known point of the backward pass:
+          MMT / TextBert encoder layers -> EncoderLayerFn.backward of that layer;  TextBert position / type / LayerNorm -> EmbedLayerNormFn.backward;
+          PrevPredEmbeddings, classifier, pointer net -> "head": when the gradients of all three MMT inputs are complete (GradBarrierFn: every
+          node downstream of them, incl. the single-node PrevPredFn and the two nn.Linear heads, has run its backward).
+        Object / OCR encoders have no trigger (they leave at finish()); the word-embedding table is exchanged row-sparsely."""
+        model, flat = self.model, self.flat
+        units = []
+
+        def add(mod_or_params, trig):
+            try:
+                units.append(flat.range_of(mod_or_params) + (trig,))
+            except (ValueError, AttributeError, IndexError):
+                pass
+
+        enc = getattr(getattr(model, "mmt", None), "encoder", None)
+        for name in ("normal_layers", "spatial_layers", "implicit_layers"):
+            for l in getattr(enc, name, []) if enc is not None else []:
+                add(l, l)
+        if getattr(model, "mmt", None) is not None and hasattr(model.mmt, "prev_pred_embeddings"):
+            add(model.mmt.prev_pred_embeddings, "head")
+        for attr in ("ocr_ptr_net", "classifier"):
+            if hasattr(model, attr):
+                add(getattr(model, attr), "head")
+        tb = getattr(model, "text_bert", None)
+        if tb is not None:
+            for l in tb.encoder.layer:
+                add(l, l)
+            emb = tb.embeddings
+
+            class _P:          # position / token-type / LayerNorm parameters of BertEmbeddings (everything but the word table)
+                @staticmethod
+                def parameters():
+                    return [emb.position_embeddings.weight, emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias]
+            add(_P, emb.LayerNorm)
+        return units
 
     def _register_regions(self, reducer):
         """Tell the reducer which address ranges become final at which explicit point of the backward pass, from the end of the buffer down
-        (SAM4C._sam_param_rank lays the parameters out in that order):
-          MMT encoder layers   -> EncoderLayerFn.backward of each layer
-          pointer net, classifier, PrevPredEmbeddings -> when the gradients of all three MMT inputs are complete (GradBarrierFn: every node
-                                  downstream of them, incl. the single-node PrevPredFn and the two nn.Linear heads, has run its backward)
-          TextBert layers      -> EncoderLayerFn.backward;   TextBert position / type / LayerNorm -> EmbedLayerNormFn.backward
-        Everything below (object / OCR encoders) leaves at finish(); the word-embedding table is exchanged row-sparsely.
-        Any piece that is missing or not where expected drops that region and everything below it (the ranges must tile up to the end)."""
-        model, flat = self.model, self.flat
-        enc = getattr(getattr(model, "mmt", None), "encoder", None)
-        layers = [l for name in ("normal_layers", "spatial_layers", "implicit_layers") for l in getattr(enc, name, [])] if enc is not None else []
-        if not layers:
+        (SAM4C._sam_param_rank lays the parameters of each optimizer group out in backward order): walk the units in descending address order
+        while they tile the buffer (the row-sparse table may sit in between) and have a trigger; adjacent "head" units merge into one region.
+        Whatever lies below the first gap leaves at finish()."""
+        units = sorted(self._units(), key=lambda u: -u[0])
+        if not units:
             return
-        ranges, owners = [flat.range_of(l) for l in layers], list(layers)
-        try:
-            lo_head, lo_enc = flat.range_of(model.ocr_ptr_net)[0], flat.range_of(enc)[0]
-            tb_layers = list(model.text_bert.encoder.layer)
-            tb_ranges = [flat.range_of(l) for l in tb_layers]
-            emb = model.text_bert.embeddings
-            lo_emb = flat.layout[emb.position_embeddings.weight._sam_index][0]
-            ok = (lo_enc == min(r[0] for r in ranges) and tb_ranges[-1][1] == lo_head and tb_ranges[0][0] > lo_emb
-                  and all(a[1] == b[0] for a, b in zip(tb_ranges[:-1], tb_ranges[1:]))
-                  and {emb.position_embeddings.weight._sam_index, emb.token_type_embeddings.weight._sam_index, emb.LayerNorm.weight._sam_index,
-                       emb.LayerNorm.bias._sam_index} == set(range(emb.position_embeddings.weight._sam_index, tb_layers[0].attention.self.query.weight._sam_index)))
-        except (AttributeError, ValueError, IndexError):
-            ok = False
-        if ok:
-            ranges += [(lo_head, lo_enc)] + tb_ranges + [(lo_emb, tb_ranges[0][0])]
-            owners += ["head"] + tb_layers + [emb.LayerNorm]
-        ids = reducer.register_regions(ranges)
-        for owner, rid in zip(owners, ids):
-            if owner == "head":
-                reducer.set_barrier(("txt", "obj", "ocr"), rid)
+        s_lo, s_hi = reducer.sparse_lo, reducer.sparse_hi
+        regions, expect = [], self.flat.numel
+        for lo, hi, trig in units:
+            if hi != expect and not (hi == s_lo and expect == s_hi and s_hi > s_lo):
+                break
+            if regions and trig == "head" and regions[-1][2] == "head" and regions[-1][0] == hi:
+                regions[-1] = (lo, regions[-1][1], "head")
             else:
-                owner._sam_region_id = rid
+                regions.append((lo, hi, trig))
+            expect = lo
+        if not regions:
+            return
+        ids = reducer.register_regions([(lo, hi) for lo, hi, _ in regions])
+        heads = []
+        for (lo, hi, trig), rid in zip(regions, ids):
+            if trig == "head":
+                heads.append(rid)
+            else:
+                trig._sam_region_id = rid
+        if heads:
+            reducer.set_barrier(("txt", "obj", "ocr"), heads)
 
-    def _sparse_table_end(self):
-        """if the word-embedding table is the first parameter of flat storage (it is for SAM4C: text_bert comes first) its gradient is
-        exchanged row-sparsely (parallel.GradReducer.sparse_rows) and the dense all-reduce starts behind it; else 0"""
+    def _sparse_table_range(self):
+        """the word-embedding table's [lo, hi) in flat storage when it can be exchanged row-sparsely (parallel.GradReducer.sparse_rows):
+        it must start its optimizer group's segment or the buffer, so that the dense ranges around it stay whole; else None"""
         emb = getattr(getattr(getattr(self.model, "text_bert", None), "embeddings", None), "word_embeddings", None)
-        if emb is None or getattr(emb.weight, "_sam_index", None) != 0 or len(self.flat.layout) < 2:
-            return 0
+        idx = getattr(getattr(emb, "weight", None), "_sam_index", None)
+        if idx is None or idx + 1 >= len(self.flat.layout):
+            return None
         emb.weight._sam_sparse_reduce = True
-        return self.flat.layout[1][0]
+        return self.flat.layout[idx][0], self.flat.layout[idx + 1][0]
 
     def current_lrs(self):
         lam = lr_lambda(self.global_step, **self.schedule)     # LambdaLR: lr(step) = base * lambda(step), stepped after opt.step()
@@ -110,21 +151,22 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.begin_step()
         parallel.active_reducer = self.reducer
-        ratio = None
+        c_global = work = None
         if self.reducer is not None and parallel.dist.is_initialized():
             # the reference normalises the loss by the number of unmasked decoding steps of the WHOLE batch (nn.DataParallel gathers the
-            # scores before the loss, task_utils.py:28-29): every rank contributes its count now (the all-reduce of one float runs
-            # underneath the forward pass) and scales its loss gradient by count_rank / count_global, so that the all-reduce SUM of the
-            # per-rank gradients is exactly the gradient of the global mean
-            c_local = batch_dict["train_loss_mask"].to(device=flat.grad.device, dtype=torch.float32).sum().clamp_(min=1.0).reshape(1)
-            c_global = c_local.clone()
-            work = parallel.dist.all_reduce(c_global, async_op=True)
+            # scores before the loss, task_utils.py:28-29): every rank contributes its RAW count now (the all-reduce of one float runs
+            # underneath the forward pass); the loss kernel divides by max(global count, 1), so the all-reduce SUM of the per-rank gradients
+            # is exactly the gradient of the global mean
+            c_global = batch_dict["train_loss_mask"].to(device=flat.grad.device, dtype=torch.float32).sum().reshape(1)
+            work = parallel.dist.all_reduce(c_global, group=self.reducer.group, async_op=True)
         model(batch_dict)
-        if self.reducer is not None and parallel.dist.is_initialized():
+        if work is not None:
             work.wait()
-            ratio = c_local / c_global
-        loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, count_ratio=ratio)
+        loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, global_count=c_global)
         loss.backward()
+        side = getattr(model, "_side_stream", None)
+        if side is not None:
+            torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
         parallel.active_reducer = None
         if self.reducer is not None:
             self.reducer.finish()                               # waits for the overlapped all-reduces
@@ -135,10 +177,37 @@ class Trainer:
         return loss.detach()
 
     # ---- checkpoint in the reference's layout (train.py:177-187) ------------------------------------------
-    def state_dict(self):
+    def _torch_optimizer(self, with_state):
+        """a torch.optim.Adam + LambdaLR over the model's parameters in the reference's group order (train.py:97-99, task_utils.py:37-57), carrying
+        this trainer's state: what `optimizer.state_dict()` / `warmup_scheduler.state_dict()` of the reference would hold at this step"""
+        groups = self.model.get_optimizer_parameters(self.base_lr)
+        opt = torch.optim.Adam(groups, lr=self.base_lr, betas=self.betas, eps=self.eps)
+        sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lambda it: lr_lambda(it, **self.schedule))
+        if with_state:
+            for p in self.flat.params:
+                i = p._sam_index
+                opt.state[p] = {"step": torch.tensor(float(self.global_step)), "exp_avg": self.flat._view(self.exp_avg, i, p).clone(),
+                                "exp_avg_sq": self.flat._view(self.exp_avg_sq, i, p).clone()}
+            sched.last_epoch = self.global_step
+            sched._step_count = self.global_step + 1
+            for g, lr in zip(opt.param_groups, self.current_lrs()):
+                g["lr"] = lr
+            sched._last_lr = [g["lr"] for g in opt.param_groups]
+        return opt, sched
+
+    def state_dict(self, current_val_score=None, epoch_id=None):
+        """the dict train.py:177-187 hands to torch.save: model_state_dict, optimizer_state_dict (torch.optim.Adam layout),
+        warmup_scheduler_state_dict (LambdaLR layout), global_step, current_val_score, epoch_id"""
+        opt, sched = self._torch_optimizer(with_state=self.global_step > 0)
         return {"model_state_dict": {k: v.detach().clone().contiguous() for k, v in self.model.state_dict().items()},
-                "optimizer_state_dict": {"exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(), "step": self.global_step},
-                "global_step": self.global_step}
+                "optimizer_state_dict": opt.state_dict(),
+                "warmup_scheduler_state_dict": sched.state_dict(),
+                "global_step": self.global_step,
+                "current_val_score": self.current_val_score if current_val_score is None else current_val_score,
+                "epoch_id": self.epoch_id if epoch_id is None else epoch_id}
+
+    def save_checkpoint(self, path, current_val_score=None, epoch_id=None):
+        torch.save(self.state_dict(current_val_score, epoch_id), path)
 
     def load_model_state_dict(self, sd):
         """accepts an optional `module.` prefix (DataParallel checkpoints, evaluator.py:182-186)"""
@@ -146,3 +215,33 @@ class Trainer:
         missing = self.model.load_state_dict(sd, strict=True)
         self.flat.refresh_shadows()
         return missing
+
+    def load_state_dict(self, ckpt, load_optimizer=True):
+        """restore from a reference-layout checkpoint dict (this package's or one written by the reference's train.py)"""
+        self.load_model_state_dict(ckpt["model_state_dict"])
+        self.global_step = int(ckpt.get("global_step", 0))
+        self.epoch_id = int(ckpt.get("epoch_id", 0))
+        self.current_val_score = ckpt.get("current_val_score")
+        osd = ckpt.get("optimizer_state_dict")
+        if load_optimizer and osd is not None and osd.get("state"):
+            opt, _ = self._torch_optimizer(with_state=False)
+            opt.load_state_dict(osd)                             # validates group sizes / shapes exactly as the reference's resume would
+            self.exp_avg.zero_(); self.exp_avg_sq.zero_()
+            steps = set()
+            for p in self.flat.params:
+                st = opt.state.get(p)
+                if not st:
+                    continue
+                i = p._sam_index
+                self.flat._view(self.exp_avg, i, p).copy_(st["exp_avg"])
+                self.flat._view(self.exp_avg_sq, i, p).copy_(st["exp_avg_sq"])
+                steps.add(int(st["step"]))
+            if len(steps) == 1:
+                self.global_step = steps.pop()                   # Adam's bias correction counts optimizer steps
+        wsd = ckpt.get("warmup_scheduler_state_dict")
+        if wsd is not None and "last_epoch" in wsd and not (load_optimizer and osd):
+            self.global_step = int(wsd["last_epoch"])
+        return self
+
+    def load_checkpoint(self, path, load_optimizer=True):
+        return self.load_state_dict(torch.load(path, map_location="cpu", weights_only=False), load_optimizer)

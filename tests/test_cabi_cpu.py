@@ -29,12 +29,14 @@ def test_library_builds_and_exports_every_declared_symbol():
 
 def test_ctypes_binding_covers_the_header():
     from sam_textvqa_amd import _capi
-    declared = set(header_functions()) - {"sam_last_error", "sam_device_info", "sam_gemm_desc"}
+    declared = set(header_functions()) - {"sam_last_error", "sam_device_info", "sam_gemm_desc", "sam_build_digest"}
     bound = set(_capi.SIGNATURES)
     assert declared <= bound, "unbound entry points: %s" % sorted(declared - bound)
     assert bound <= set(header_functions()), "bound but undeclared: %s" % sorted(bound - set(header_functions()))
     l = _capi.lib()
-    assert l.sam_abi_version() == 1
+    assert l.sam_abi_version() == 2
+    import sam_textvqa_amd._build as b
+    assert l.sam_build_digest().decode() == b._digest()          # the binary that is loaded is the one built from the sources in the tree
     assert _capi.call("sam_attn_words_per_row", 182) == 6 and _capi.call("sam_attn_words_per_row", 20) == 1
     assert _capi.call("sam_attn_words_per_row", 350) == 12 and _capi.call("sam_attn_words_per_row", 385) == -1
 
@@ -86,3 +88,18 @@ def test_plain_cxx_host_program_links_against_the_c_abi(tmp_path):
     from tests.cabi_host import build_host_smoke
     exe = build_host_smoke(tmp_path)
     assert os.path.exists(exe)
+
+
+def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
+    """_capi.lib() compares the digest compiled into the binary with the tree's: a stale libsam_hip.so never runs against changed signatures"""
+    import sam_textvqa_amd._build as b
+    from sam_textvqa_amd import _capi
+    _capi.lib()
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setattr(b, "build", lambda *a, **k: b.LIB)                # pretend the rebuild was skipped ...
+    monkeypatch.setattr(b, "_digest", lambda: "0" * 64)                  # ... although the sources changed
+    with pytest.raises(_capi.SamHipError, match="other sources"):
+        _capi.lib()
+    monkeypatch.setattr(b, "build", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("hipcc failed on gemm.hip")))
+    with pytest.raises(_capi.SamHipError, match="could not be"):
+        _capi.lib()                                                        # a failed rebuild is an error even though an older .so exists

@@ -90,3 +90,81 @@ def test_reducer_bucket_plan_and_region_order():
     red2 = GradReducer(torch.zeros(1000), bucket_bytes=4 * 256, dense_lo=40)     # row-sparse table in [0, 40): outside every bucket
     red2.register_regions([(500, 1000)])
     assert red2.buckets == [(744, 1000), (500, 744), (244, 500), (40, 244)]
+
+
+def test_reducer_with_the_sparse_table_in_the_middle():
+    """three optimizer groups (text_bert_init_from_bert_base): the word-embedding table sits between the default group and the rest of
+    TextBert; it is in no dense bucket, and regions may continue below it"""
+    from sam_textvqa_amd.parallel import GradReducer
+    red = GradReducer(torch.zeros(1000), bucket_bytes=4 * 200, sparse_range=(300, 400))
+    assert red.buckets == [(800, 1000), (600, 800), (400, 600), (100, 300), (0, 100)] and red.dense_lo == 0
+    ids = red.register_regions([(250, 300), (400, 700), (700, 1000)])      # a region below the table, two above
+    assert ids == [2, 1, 0]
+    assert red.buckets == [(800, 1000), (600, 800), (400, 600), (250, 300), (50, 250), (0, 50)]
+    red.set_barrier(("a", "b"), [ids[0], ids[2]])       # one barrier may finalise several (non-adjacent) regions
+    red.barrier_hit("a"); assert red.next_bucket == 0
+    red.barrier_hit("b"); assert red.next_bucket == 1     # [800,1000) final; [250,300) is too but must wait for everything above it
+    red.mark_done(ids[1]); assert red.next_bucket == 4    # ... and leaves as soon as the middle region is done
+    red.finish(); assert red.next_bucket == 6
+    import pytest
+    with pytest.raises(ValueError):
+        GradReducer(torch.zeros(1000), sparse_range=(300, 400)).register_regions([(200, 290), (400, 1000)])    # a real gap
+
+
+def test_three_optimizer_groups_when_text_bert_starts_from_bert_base(tmp_path):
+    """sa_m4c.py:74-85,349-371: [default lr | text_bert @ lr_scale_text_bert | mmt @ lr_scale_mmt], weights from a local bert-base file"""
+    import sam_textvqa_amd.modules as M
+    mcfg, tcfg = OC.sam4c_configs("sam4c_small_c3")
+    kw = dict(mcfg.__dict__, hidden_size=768, intermediate_size=128, ptr_query_size=768)
+    tkw = dict(tcfg.__dict__, text_bert_init_from_bert_base=True, lr_scale_text_bert=0.1)
+    plain = M.SAM4C(M.BertConfig.from_dict(kw), M.BertConfig.from_dict(tcfg.__dict__), num_answers=30, bos_idx=1)
+    # a stand-in "bert-base-uncased" file in the usual key layout (bert. prefix, 12 layers, old gamma/beta LayerNorm names)
+    fake = {}
+    for k, v in plain.text_bert.state_dict().items():
+        fake["bert." + k.replace("LayerNorm.weight", "LayerNorm.gamma").replace("LayerNorm.bias", "LayerNorm.beta")] = torch.randn_like(v)
+    fake["bert.encoder.layer.11.output.dense.bias"] = torch.zeros(768)
+    fake["cls.predictions.bias"] = torch.zeros(5)
+    path = str(tmp_path / "pytorch_model.bin")
+    torch.save(fake, path)
+    model = M.SAM4C(M.BertConfig.from_dict(kw), M.BertConfig.from_dict(dict(tkw, text_bert_pretrained_path=str(tmp_path))), num_answers=30, bos_idx=1)
+    assert torch.equal(model.text_bert.embeddings.LayerNorm.weight, fake["bert.embeddings.LayerNorm.gamma"])
+    assert torch.equal(model.text_bert.encoder.layer[0].attention.self.query.weight, fake["bert.encoder.layer.0.attention.self.query.weight"])
+    groups = model.get_optimizer_parameters(1e-4)
+    n_tb, n_mmt = len(list(model.text_bert.parameters())), len(list(model.mmt.parameters()))
+    assert [len(g["params"]) for g in groups] == [len(list(model.parameters())) - n_tb - n_mmt, n_tb, n_mmt]
+    assert "lr" not in groups[0] and abs(groups[1]["lr"] - 1e-5) < 1e-12 and groups[2]["lr"] == 1e-4
+    assert list(model.state_dict()) == list(plain.state_dict())          # same checkpoint layout either way
+    # without a local file the flag is still accepted (the weights then come from a checkpoint)
+    m2 = M.SAM4C(M.BertConfig.from_dict(kw), M.BertConfig.from_dict(tkw), num_answers=30, bos_idx=1)
+    assert len(m2.get_optimizer_parameters(1e-4)) == 3
+
+
+def test_shipped_reference_configs_build_the_model_unchanged():
+    """every YAML under /root/reference/configs -> BertConfig.from_dict -> SAM4C(mmt_config, text_bert_config) exactly as train.py:92-94 does
+    (build container only: the reference tree does not travel to the GPU box)"""
+    import glob, os
+    import pytest
+    files = sorted(glob.glob("/root/reference/configs/*.yml"))
+    if not files:
+        pytest.skip("/root/reference is not present here")
+    import yaml
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.registry import registry
+    registry.answer_vocab, registry.BOS_IDX = list(range(5000)), 1         # what the dataset code puts there (sa_m4c.py:169,291)
+    assert len(files) == 4
+    for f in files:
+        cfg = yaml.safe_load(open(f))
+        mmt_config, text_bert_config = M.BertConfig.from_dict(cfg["SA-M4C"]), M.BertConfig.from_dict(cfg["TextBERT"])
+        model = M.SAM4C(mmt_config, text_bert_config)
+        groups = model.get_optimizer_parameters(cfg["lr"])
+        assert [len(g["params"]) for g in groups] == [22, 53, 104], os.path.basename(f)        # SURVEY.md App. B probe: 75 + 104 without the flag
+        assert "lr" not in groups[0] and abs(groups[1]["lr"] - 0.1 * cfg["lr"]) < 1e-12 and groups[2]["lr"] == cfg["lr"]
+        assert sum(p.numel() for p in model.parameters()) == 96_633_224, os.path.basename(f)          # 96.63 M (SURVEY.md §8a a-18)
+        enc = model.mmt.encoder
+        assert (len(enc.normal_layers), len(enc.spatial_layers)) == (2, 4) and enc.mix_list == cfg["SA-M4C"]["mix_list"]
+        # the shipped c5 file asks the MODEL for share5 heads while its top-level (dataset) mix_list says share3: the reference dies with a bare
+        # KeyError('5') at sa_m4c.py:747; this build names the mismatch
+        if enc.mix_list[-1] != cfg["mix_list"][-1]:
+            bd = {"spatial_adj_matrices": {"3": None, "1": None}}
+            with pytest.raises(KeyError, match="mix_list"):
+                enc._adjacency_for(bd, enc.mix_list[-1])

@@ -217,6 +217,65 @@ def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
     tr.load_model_state_dict({"module." + k: v for k, v in sd["model_state_dict"].items()})
 
 
+@pytest.mark.parametrize("from_bert_base", [False, True])
+def test_checkpoint_dict_is_the_reference_layout_and_resumes_exactly(from_bert_base, tmp_path):
+    """train.py:177-187: model_state_dict, optimizer_state_dict (torch.optim.Adam layout over the reference's param groups), warmup_scheduler_state_dict
+    (LambdaLR), global_step, current_val_score, epoch_id.  The dict loads into a plain torch Adam / LambdaLR built the reference's way
+    (task_utils.py:37-57), and a fresh trainer resumed from the file continues bit-identically to the uninterrupted run.
+    from_bert_base: the shipped YAMLs' three optimizer groups (sa_m4c.py:74-85)."""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch, mmt_config_dict, text_bert_config_dict
+    from sam_textvqa_amd.trainer import Trainer, lr_lambda
+
+    def build():
+        torch.manual_seed(5)
+        md = mmt_config_dict(3, ("n", "s"))
+        md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, obj_drop=0.0, ocr_drop=0.0)
+        td = dict(text_bert_config_dict(), num_hidden_layers=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500,
+                  text_bert_init_from_bert_base=from_bert_base, lr_scale_text_bert=0.1)
+        return M.SAM4C(M.BertConfig.from_dict(md), M.BertConfig.from_dict(td), num_answers=300, bos_idx=1)
+
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    tr = Trainer(build(), base_lr=1e-3, seed=3)
+    assert len(tr.group_lr) == (3 if from_bert_base else 2)
+    for _ in range(3):
+        tr.step(clone_batch(batch))
+    path = str(tmp_path / "best_model.tar")
+    tr.save_checkpoint(path, current_val_score=0.42, epoch_id=7)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck) == {"model_state_dict", "optimizer_state_dict", "warmup_scheduler_state_dict", "global_step", "current_val_score", "epoch_id"}
+    assert ck["global_step"] == 3 and ck["current_val_score"] == 0.42 and ck["epoch_id"] == 7
+    # the reference's own objects accept it
+    plain = build()
+    plain.load_state_dict(ck["model_state_dict"])
+    groups = plain.get_optimizer_parameters(1e-3)
+    opt = torch.optim.Adam(groups, lr=1e-3)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, lr_lambda=lr_lambda)
+    opt.load_state_dict(ck["optimizer_state_dict"])
+    sched.load_state_dict(ck["warmup_scheduler_state_dict"])
+    assert [len(g["params"]) for g in opt.param_groups] == [len(g["params"]) for g in groups] and sched.last_epoch == 3
+    want = [1e-3 * lr_lambda(3) * (0.1 if (from_bert_base and i == 1) else 1.0) for i in range(len(groups))]
+    assert all(abs(g["lr"] - w) < 1e-12 for g, w in zip(opt.param_groups, want))
+    names = {id(p): n for n, p in plain.named_parameters()}
+    mine = dict(tr.model.named_parameters())
+    for g in opt.param_groups:
+        for p in g["params"]:
+            st, q = opt.state[p], mine[names[id(p)]]
+            assert int(st["step"]) == 3 and st["exp_avg"].shape == p.shape
+            assert torch.equal(st["exp_avg"], tr.flat._view(tr.exp_avg, q._sam_index, q).cpu())
+            assert torch.equal(st["exp_avg_sq"], tr.flat._view(tr.exp_avg_sq, q._sam_index, q).cpu())
+    # resume: same trajectory as the uninterrupted run, bit for bit (dropout is off; the sparse-table scatter has a fixed order only
+    # under a reducer, the single-process word-embedding scatter uses atomics -> compare with a tolerance of a few ulps there)
+    tr2 = Trainer(build(), base_lr=1e-3, seed=3).load_checkpoint(path)
+    assert tr2.global_step == 3 and tr2.epoch_id == 7 and tr2.current_val_score == 0.42
+    assert torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.flat.flat, tr.flat.flat)
+    a = [tr.step(clone_batch(batch)).item() for _ in range(2)]
+    b = [tr2.step(clone_batch(batch)).item() for _ in range(2)]
+    assert all(abs(x - y) <= 1e-5 * abs(x) for x, y in zip(a, b)), (a, b)
+    assert (tr.flat.flat - tr2.flat.flat).abs().max().item() < 1e-5
+
+
 def test_greedy_decode_eval_matches_oracle():
     """eval(): BOS-seeded greedy loop, 12 re-forwards (sa_m4c.py:285-302); scores close, decoded indices (argmax of near-equal
     logits may flip under bf16) agree on the overwhelming majority of steps"""
@@ -274,12 +333,25 @@ os.environ["SAM_FORCE_DIST"] = "1"
 os.environ["SAM_REDUCER_CHECK"] = "1"                   # every released bucket is re-checked at finish(): a premature release raises
 parallel.init_distributed()                               # 1-rank RCCL group: all-reduce / all-gather really go through RCCL
 res = []
+three = os.environ.get("SAM_TEST_THREE_GROUPS") == "1"
 for dist_on in (True, False):
     os.environ["SAM_FORCE_DIST"] = "1" if dist_on else "0"
     model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+    if three:        # the shipped YAMLs: TextBert is its own optimizer group (sa_m4c.py:74-85) -> [default | text_bert | mmt] in flat storage
+        model.finetune_modules.insert(0, {"module": model.text_bert, "lr_scale": 0.1})
     tr = Trainer(model, base_lr=1e-3, seed=3)
     assert (tr.reducer is not None) == dist_on
-    if dist_on:
+    if dist_on and three:
+        w = model.text_bert.embeddings.word_embeddings.weight
+        red, flat = tr.reducer, tr.flat
+        lo_tb = flat.range_of(model.text_bert)[0]
+        assert len(tr.group_lr) == 3 and (red.sparse_lo, red.sparse_hi) == (lo_tb, flat.layout[w._sam_index + 1][0]) and red.sparse_lo > 0 and w._sam_sparse_reduce
+        assert red.sparse_hi - red.sparse_lo >= w.numel()
+        assert all(hi <= red.sparse_lo or lo >= red.sparse_hi for lo, hi in red.buckets)            # the table is in no dense bucket
+        # regions from the end: 2 MMT layers | PrevPredEmbeddings (barrier) | 1 TextBert layer | its embeddings | [table] | classifier + pointer net (barrier)
+        assert len(red.regions) == 6 and red.barrier_regions == [2, 5] and red.regions[4][0] == red.sparse_hi and red.regions[5][1] == red.sparse_lo
+        assert red.regions[5][0] == flat.range_of(model.ocr_ptr_net)[0] > flat.range_of(model.linear_ocr_feat_to_mmt_in)[0]
+    if dist_on and not three:
         w = model.text_bert.embeddings.word_embeddings.weight
         assert tr.reducer.dense_lo == tr.flat.layout[1][0] >= w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
         assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo and tr.reducer.check
@@ -316,16 +388,18 @@ print("DIST_OK")
 """
 
 
-def test_rccl_path_one_rank_matches_plain_trainer(tmp_path):
+@pytest.mark.parametrize("three_groups", [False, True])
+def test_rccl_path_one_rank_matches_plain_trainer(tmp_path, three_groups):
     """SAM_FORCE_DIST=1: bucketed all-reduce on the side stream + the row-sparse word-embedding exchange run through RCCL in a 1-rank
-    group and must train exactly like the reducer-less path"""
+    group and must train exactly like the reducer-less path.  three_groups: the shipped configs' optimizer layout, where the table sits in
+    the middle of the flat buffer and the heads below it"""
     import subprocess
     import sys
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
+               HSA_ENABLE_IPC_MODE_LEGACY="0", SAM_TEST_THREE_GROUPS="1" if three_groups else "0")
     r = subprocess.run([sys.executable, "-c", _DIST_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
     assert r.returncode == 0 and "DIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 

@@ -153,3 +153,25 @@ def test_gradnorm_and_adam_match_torch():
         ref = torch.cat([ref_p[0].detach(), ref_p[1].detach()])
         assert torch.allclose(p.cpu(), ref, rtol=1e-5, atol=1e-6), (p.cpu() - ref).abs().max()
         assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
+
+
+def test_sorted_embedding_backward_is_deterministic_and_equals_index_add():
+    """sam_embedding_bwd_sorted (data-parallel row-sparse exchange): one writer per table row, duplicates summed in list order"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    T, D, rows = 777, 768, 97
+    ids = torch.randint(0, rows, (T,), generator=g)
+    ids[:40] = 0                              # padding rows
+    dy = torch.randn(T, D, generator=g).to(torch.bfloat16)
+    order = torch.sort(ids, stable=True)
+    base = torch.randn(rows, D, generator=g)
+    outs = []
+    for _ in range(2):
+        tab = base.clone().cuda()
+        ops.embedding_bwd_sorted(dy[order.indices].cuda().contiguous(), order.values.cuda(), tab, padding_idx=0)
+        outs.append(tab.cpu())
+    assert torch.equal(outs[0], outs[1])
+    ref = base.clone().double()
+    keep = ids != 0
+    ref.index_add_(0, ids[keep], dy[keep].double())
+    assert (outs[0].double() - ref).abs().max().item() < 1e-4 and torch.equal(outs[0][0], base[0])
