@@ -51,7 +51,7 @@ def profile_step(trainer, batch):
     torch.cuda.synchronize()
     torch.cuda._sleep(int(40e6))     # ~20 ms of GPU spin: the host enqueues the whole step ahead of the GPU, so every
     capi.profiler = []               # event pair brackets kernel execution only (no host-launch gaps inside the brackets)
-    trainer.step(clone_batch(batch))
+    trainer._eager_step(clone_batch(batch))       # the per-kernel route (no graph replay, no coarse C++ ops): one event pair per launch
     torch.cuda.synchronize()
     recs, capi.profiler = capi.profiler, None
     agg = {}
@@ -175,6 +175,7 @@ def main():
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--shape", default="c3", choices=["c3", "stress"],
                     help="c3: T=20,100 obj,50 OCR,12 dec, layers n,n,s,s,s,s (BASELINE configs 1-4); stress: 200 obj,100 OCR,30 dec, 12 layers (config 5)")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured hipGraph (1 GPU only; N > 1 is always eager)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -190,7 +191,7 @@ def main():
     shape = SHAPES[args.shape]
     layers = ("n", "n", "s", "s", "s", "s") if args.shape == "c3" else ("n", "n") + ("s",) * 10
     model = build_model(args.context, layers, args.vocab, shape)
-    trainer = Trainer(model, seed=1234 + rank)
+    trainer = Trainer(model, seed=1234 + rank, use_graph=(world == 1 and not args.no_graph))
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
 
     for _ in range(args.warmup):

@@ -79,8 +79,11 @@ int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uin
  *   SAM_EPI_BIAS_GELU         aux_out = acc + bias ; C = gelu_erf(aux_out)        BertIntermediate via :678
  *   SAM_EPI_BIAS_DROPOUT_RES  C = dropout(acc + bias) + residual[m,n]             BertSelfOutput :653 / BertOutput :680 (pre-LN)
  *   SAM_EPI_DGELU             C = acc * gelu_erf'(aux_in[m,n])                    backward of BertIntermediate
+ *   SAM_EPI_BIAS_GELU_GRAD    aux_out = gelu_erf'(acc + bias) ; C = gelu_erf(acc + bias)     BertIntermediate in TRAINING: the derivative shares the
+ *                             exponential with the activation (two extra FMAs); the backward then needs no transcendental at all:
+ *   SAM_EPI_MUL_AUX           C = acc * aux_in[m,n]                               backward of BertIntermediate from the stored derivative
  * bias may be NULL (treated as 0); dropout uses Philox4x32-10 on (row, col/8) so the backward regenerates it. */
-enum { SAM_EPI_NONE = 0, SAM_EPI_BIAS = 1, SAM_EPI_BIAS_GELU = 2, SAM_EPI_BIAS_DROPOUT_RES = 3, SAM_EPI_DGELU = 4 };
+enum { SAM_EPI_NONE = 0, SAM_EPI_BIAS = 1, SAM_EPI_BIAS_GELU = 2, SAM_EPI_BIAS_DROPOUT_RES = 3, SAM_EPI_DGELU = 4, SAM_EPI_BIAS_GELU_GRAD = 5, SAM_EPI_MUL_AUX = 6 };
 typedef struct sam_gemm_desc {
   int32_t M, N, K;
   int32_t a_kcontig, b_kcontig;
@@ -189,7 +192,19 @@ int64_t sam_sumsq_ws_bytes(void);
 int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, void* stream);
 int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
                   float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream);
+/* the same update with the step's schedule in DEVICE memory: dev_sched = [lr of segment 0..nseg-1, 1 - beta1^t, 1 - beta2^t] (fp32).  A launch
+ * captured in a hipGraph freezes its by-value arguments; this form lets every replay apply the current learning rates / bias corrections. */
+int sam_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                      float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, void* stream);
 int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- dropout RNG state in device memory (hipGraph capture) ----
+ * Every dropout site takes (seed, offset) BY VALUE (counter-based: the backward regenerates the forward's mask from the same pair).  Launches
+ * captured in a hipGraph would replay the same masks for ever; with a device-side state set, kernels launched afterwards (from any thread of
+ * the process: the autograd engine launches the backward from its own) use
+ * key = state[0] (if non-zero, else the by-value seed) and offset = state[1] + the by-value offset, read at execution time -- the graph (or the
+ * host, between replays) advances state[1].  dev_state: uint64[2] in device memory, NULL switches back to by-value only. */
+void sam_set_rng_state(const unsigned long long* dev_state);
 
 #ifdef __cplusplus
 }

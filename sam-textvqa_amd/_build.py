@@ -89,5 +89,41 @@ def build(force=False, verbose=False):
     return LIB
 
 
+# ---- PyTorch-ROCm custom ops (csrc_torch/sam_torch_ops.cpp): TORCH_LIBRARY registration + coarse per-layer entry points over the C ABI ----
+TORCH_OPS_SRC = os.path.join(PKG, "csrc_torch", "sam_torch_ops.cpp")
+TORCH_OPS_LIB = os.path.join(LIB_DIR, "libsam_torch_ops.so")
+CXX = os.environ.get("CXX", "g++")
+
+
+def build_torch_ops(force=False, verbose=False):
+    """g++ against the torch headers (no device code in this file); links libsam_hip.so from its own directory ($ORIGIN)"""
+    import torch
+    from torch.utils.cpp_extension import include_paths, library_paths
+    build()
+    h = hashlib.sha256(open(TORCH_OPS_SRC, "rb").read())
+    h.update(open(os.path.join(os.path.dirname(PKG), "include", "sam_hip.h"), "rb").read())
+    h.update(torch.__version__.encode())
+    dig, stamp = h.hexdigest(), TORCH_OPS_LIB + ".sha256"
+    if not force and os.path.exists(TORCH_OPS_LIB) and os.path.exists(stamp) and open(stamp).read().strip() == dig:
+        return TORCH_OPS_LIB
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = [CXX, "-O2", "-std=c++17", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+           "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI), TORCH_OPS_SRC, "-o", TORCH_OPS_LIB,
+           "-I", os.path.join(os.path.dirname(PKG), "include"), "-I", os.path.join(rocm, "include")]
+    cmd += ["-I" + i for i in include_paths()] + ["-L" + l for l in library_paths()] + ["-L", LIB_DIR, "-lsam_hip", "-Wl,-rpath,$ORIGIN",
+                                                                                         "-lc10", "-ltorch_cpu", "-ltorch", "-lc10_hip", "-ltorch_hip"]
+    if verbose:
+        print(" ".join(cmd))
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("building the torch ops failed:\n%s" % r.stdout.decode(errors="replace")[-4000:])
+    with open(stamp, "w") as f:
+        f.write(dig)
+    return TORCH_OPS_LIB
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    print(build_torch_ops(force=True, verbose=True))

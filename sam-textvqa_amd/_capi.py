@@ -22,7 +22,7 @@ class GemmDesc(C.Structure):
                 ("defer_reduce", C.c_int32), ("split_k_used", C.c_int32)]
 
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU = range(5)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = range(7)
 
 # name -> argtypes (all return int status except where noted)
 SIGNATURES = {
@@ -58,9 +58,11 @@ SIGNATURES = {
     "sam_sumsq_ws_bytes": [],
     "sam_sumsq_f32": [_vp, _i64, _vp, _vp, _vp],
     "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],
+    "sam_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, _vp],
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "sam_set_rng_state": [_vp],
 }
-NO_STATUS = {"sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 RET_I64 = {"sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 
 _lib = None

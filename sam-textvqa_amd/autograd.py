@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import _capi as capi
-from . import ops, parallel
+from . import ops, parallel, torchops
 from .params import FlatParams, flat_of
 
 BF16 = torch.bfloat16
@@ -292,25 +292,41 @@ class EncoderLayerFn(Function):
         heads = att.num_attention_heads
         scale = 1.0 / math.sqrt(att.attention_head_size)
         seeds = [dropout_clock.next() for _ in range(3)]
+        ctx.layer, ctx.batch, ctx.p_attn, ctx.p_hid, ctx.seeds, ctx.scale = layer, batch, p_attn, p_hid, seeds, scale
+        if coarse_ops_active() and x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1:
+            # one custom-op call enqueues the whole layer from C++ (csrc_torch/sam_torch_ops.cpp): same kernels, same order, a tenth of the host time
+            outs = torchops.ns().encoder_layer_fwd(x, allow, _layer_params(layer), batch, heads, scale, p_attn, p_hid, [v for sd in seeds for v in sd],
+                                                   so.LayerNorm.variance_epsilon, out.LayerNorm.variance_epsilon)
+            ctx.save_for_backward(*outs[1:], allow)
+            ctx.coarse = True
+            return outs[0]
+        ctx.coarse = False
         qkv = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
         ctxv, lse2, keep = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0])
         z1 = ops.gemm(ctxv, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x, p_drop=p_hid,
                       seed=seeds[1][0], offset=seeds[1][1])
         a, mean1, rstd1 = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
         pre = torch.empty((x.shape[0], inter.dense.weight.shape[0]), dtype=BF16, device=x.device)
-        h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU, bias=inter.dense.bias, aux_out=pre)
+        h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=inter.dense.bias, aux_out=pre)     # pre := gelu'(a W1^T + b1)
         z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a, p_drop=p_hid,
                       seed=seeds[2][0], offset=seeds[2][1])
         y, mean2, rstd2 = ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)
         ctx.save_for_backward(x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow)
-        ctx.layer, ctx.batch, ctx.p_attn, ctx.p_hid, ctx.seeds, ctx.scale = layer, batch, p_attn, p_hid, seeds, scale
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
         layer, p_hid, seeds = ctx.layer, ctx.p_hid, ctx.seeds
         att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        if ctx.coarse:
+            *saved, allow = ctx.saved_tensors
+            dx = torchops.ns().encoder_layer_bwd(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch, att.num_attention_heads, ctx.scale,
+                                                 ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]))
+            rid = getattr(layer, "_sam_region_id", None)
+            if rid is not None and parallel.active_reducer is not None:
+                parallel.active_reducer.mark_done(rid)
+            return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
+        x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
         wqkv, _, dwqkv, dbqkv = _fused_qkv(att)
         if dy.dtype != BF16 or not dy.is_contiguous():
             dy = dy.to(BF16).contiguous()
@@ -318,7 +334,7 @@ class EncoderLayerFn(Function):
         dz2, dy2 = ops.layernorm_bwd(dy, z2, mean2, rstd2, out.LayerNorm.weight, out.LayerNorm.weight.grad, out.LayerNorm.bias.grad,
                                      dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1])
         wgrads = [(dy2, h, out.dense.weight.grad, None)]          # the four weight gradients go out as ONE grouped launch at the end
-        dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=pre)
+        dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=pre)
         # ---- intermediate: h = gelu(a W1^T + b1)
         wgrads.append((dpre, a, inter.dense.weight.grad, inter.dense.bias.grad))          # bias gradient fused into the wgrad
         da = ops.gemm(dpre, _w(inter.dense.weight), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz2)   # + residual path
@@ -336,6 +352,34 @@ class EncoderLayerFn(Function):
         if rid is not None and parallel.active_reducer is not None:
             parallel.active_reducer.mark_done(rid)            # this layer's gradients are final: its bucket may go out now
         return dx, None, None, None, None, None, None
+
+
+def coarse_ops_active():
+    """the C++ per-layer ops are used unless switched off (SAM_COARSE_OPS=0) or bench.py's per-kernel event profiler is recording"""
+    return torchops.enabled() and capi.profiler is None
+
+
+def _layer_params(layer):
+    """the 12 operands of one encoder layer in the order csrc_torch/sam_torch_ops.cpp expects (cached: the views never move)"""
+    c = getattr(layer, "_sam_coarse_params", None)
+    if c is None:
+        att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        wqkv, bqkv, _, _ = _fused_qkv(att)
+        c = layer._sam_coarse_params = [wqkv, bqkv, _w(so.dense.weight), so.dense.bias.data, so.LayerNorm.weight.data, so.LayerNorm.bias.data,
+                                        _w(inter.dense.weight), inter.dense.bias.data, _w(out.dense.weight), out.dense.bias.data,
+                                        out.LayerNorm.weight.data, out.LayerNorm.bias.data]
+    return c
+
+
+def _layer_grads(layer):
+    c = getattr(layer, "_sam_coarse_grads", None)
+    if c is None:
+        att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        _, _, dwqkv, dbqkv = _fused_qkv(att)
+        c = layer._sam_coarse_grads = [dwqkv, dbqkv, so.dense.weight.grad, so.dense.bias.grad, so.LayerNorm.weight.grad, so.LayerNorm.bias.grad,
+                                       inter.dense.weight.grad, inter.dense.bias.grad, out.dense.weight.grad, out.dense.bias.grad,
+                                       out.LayerNorm.weight.grad, out.LayerNorm.bias.grad]
+    return c
 
 
 def encoder_layer(x2d, layer, allow, batch, training):

@@ -76,6 +76,7 @@ struct AttnArgs {
   int B, N, H, NW, nkt, q_begin;   // q_begin: first query row to compute (forward only; rounded down to a 16-row tile)
   float scale, scale_log2, p_drop, inv_keep;
   unsigned thr16, seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* rng_state;
 };
 
 // --------------------------------------------------------------------------------------------
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnAr
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  unsigned seed_lo = a.seed_lo, seed_hi = a.seed_hi, off_lo = a.off_lo, off_hi = a.off_hi;
+  if (a.thr16) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
   for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += 4) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     bf16x8 qf[2];
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnAr
     for (int w = 0; w < NKT / 2; ++w) {
       float v8[8] = {s[2 * w][0], s[2 * w][1], s[2 * w][2], s[2 * w][3], s[2 * w + 1][0], s[2 * w + 1][1], s[2 * w + 1][2], s[2 * w + 1][3]};
       if (a.thr16 != 0) {
-        const u32x4 rn = dropout_bits128((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), a.off_lo, a.off_hi, a.seed_lo, a.seed_hi);
+        const u32x4 rn = dropout_bits128((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), off_lo, off_hi, seed_lo, seed_hi);
         const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
         unsigned bits = 0;
 #pragma unroll
@@ -439,6 +442,7 @@ static int attn_fwd_impl(const void* qkv, const uint32_t* allow, int64_t allow_s
   a.qkv = (const bf16_t*)qkv; a.out_w = (bf16_t*)out; a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h;
   a.lse2_w = lse2; a.keep_w = keep; a.q_begin = q_begin;
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.off_lo = (unsigned)offset; a.off_hi = (unsigned)(offset >> 32);
+  a.rng_state = sam_get_rng_state();
   hipStream_t st = (hipStream_t)stream;
   switch (a.nkt) {
     case 2: return launch_fwd<2>(a, st);

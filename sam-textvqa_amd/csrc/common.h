@@ -19,6 +19,8 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 #define SAM_ERR_UNSUPPORTED (-2)  // valid request this build has no kernel for
 
 extern "C" void sam_set_error(const char* fmt, ...);
+// dropout RNG state in DEVICE memory (thread-local pointer set by sam_set_rng_state; NULL = seeds and offsets are taken by value only)
+extern "C" const unsigned long long* sam_get_rng_state(void);
 
 #define SAM_REQUIRE(cond, ...)                    \
   do {                                            \
@@ -76,6 +78,16 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// Captured (hipGraph) launches freeze their by-value arguments: with a device-side state {seed, offset_base} every replay still draws fresh
+// masks -- the effective key is state[0] (when non-zero) and the effective offset is state[1] + the by-value offset of the dropout site.
+__device__ __forceinline__ void rng_resolve(const unsigned long long* st, unsigned& seed_lo, unsigned& seed_hi, unsigned& off_lo, unsigned& off_hi) {
+  if (st) {
+    const unsigned long long s = st[0], o = st[1] + (((unsigned long long)off_hi << 32) | off_lo);
+    if (s) { seed_lo = (unsigned)s; seed_hi = (unsigned)(s >> 32); }
+    off_lo = (unsigned)o; off_hi = (unsigned)(o >> 32);
+  }
+}
+
 // Philox4x32-10 (Salmon et al. 2011), counter-based: same (key, counter) -> same bits in fwd and bwd.
 struct u32x4 { unsigned x, y, z, w; };
 __device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
@@ -125,6 +137,13 @@ __device__ __forceinline__ float gelu_phi_and_cdf(float x, float& cdf) {   // re
 __device__ __forceinline__ float gelu_erf(float x) {
   float cdf;
   gelu_phi_and_cdf(x, cdf);
+  return x * cdf;
+}
+// activation and derivative from one exponential (training forward: the derivative is what the backward needs, not the pre-activation)
+__device__ __forceinline__ float gelu_erf_and_grad(float x, float& grad) {
+  float cdf;
+  const float e = gelu_phi_and_cdf(x, cdf);
+  grad = cdf + x * 0.39894228040143268f * e;
   return x * cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {

@@ -138,6 +138,7 @@ struct Gather2Args {
   const bf16_t* ocr; int64_t ld_ocr; int n_ocr;
   const int64_t* inds; int B, S, D;
   unsigned thr16; float inv_keep; unsigned seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* rng_state;
 };
 __device__ __forceinline__ int64_t clamp_ind(int64_t i, int n) { return i < 0 ? 0 : (i >= n ? n - 1 : i); }
 
@@ -145,6 +146,7 @@ __device__ __forceinline__ int64_t clamp_ind(int64_t i, int n) { return i < 0 ? 
 __global__ __launch_bounds__(256) void gather2_add_fwd_kernel(Gather2Args a, const bf16_t* emb, int64_t ld_emb, bf16_t* out, int64_t ldo) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.B * a.S) return;
+  if (a.thr16) rng_resolve(a.rng_state, a.seed_lo, a.seed_hi, a.off_lo, a.off_hi);
   const int64_t ind = clamp_ind(a.inds[r], a.V + a.n_ocr);
   const bf16_t* src = ind < a.V ? a.ans + ind * a.ld_ans : a.ocr + ((int64_t)(r / a.S) * a.n_ocr + (ind - a.V)) * a.ld_ocr;
   for (int c = lane; 4 * c < a.D; c += 64) {
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(256) void gather2_add_bwd_kernel(Gather2Args a, con
                                                               int64_t ld_docr, bf16_t* d_emb, int64_t ld_demb) {
   const int lane = threadIdx.x & 63, r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= a.B * a.S) return;
+  if (a.thr16) rng_resolve(a.rng_state, a.seed_lo, a.seed_hi, a.off_lo, a.off_hi);
   const int64_t ind = clamp_ind(a.inds[r], a.V + a.n_ocr);
   float* dst = ind < a.V ? d_ans + ind * ld_dans : d_ocr + ((int64_t)(r / a.S) * a.n_ocr + (ind - a.V)) * ld_docr;
   for (int c = lane; 4 * c < a.D; c += 64) {
@@ -186,7 +189,7 @@ int fill_gather_args(Gather2Args& a, const void* ans, int64_t ld_ans, int V, con
   SAM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sam_gather2_add: p_drop out of range");
   const unsigned thr16 = dropout_thr16(p_drop);
   a = Gather2Args{(const bf16_t*)ans, ld_ans, V, (const bf16_t*)ocr, ld_ocr, n_ocr, inds, B, S, D, thr16, thr16 ? 1.0f / (1.0f - (float)thr16 / 65536.0f) : 1.0f,
-                  (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32)};
+                  (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), sam_get_rng_state()};
   return SAM_OK;
 }
 

@@ -250,6 +250,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
 template <int EPI, typename OutT>
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, int S, GemmArgs p) {
   const int64_t mn4 = (int64_t)p.M * p.N / 4, MN = (int64_t)p.M * p.N;
+  unsigned seed_lo = p.seed_lo, seed_hi = p.seed_hi, off_lo = p.off_lo, off_hi = p.off_hi;
+  if (EPI == SAM_EPI_BIAS_DROPOUT_RES) rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
   for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < mn4; i4 += (int64_t)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4*>(ws)[i4];
     for (int s = 1; s < S; ++s) {
@@ -259,7 +261,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, i
     const int64_t e = i4 * 4;
     const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
     float v[4] = {a.x, a.y, a.z, a.w};
-    if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+    if (EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_BIAS_GELU_GRAD) {
       if (p.bias) {
         const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
@@ -270,14 +272,24 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, i
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
     }
+    if (EPI == SAM_EPI_BIAS_GELU_GRAD) {
+      float d[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
+      *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+    }
     if (EPI == SAM_EPI_DGELU) {
       const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
       v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
       v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
     }
+    if (EPI == SAM_EPI_MUL_AUX) {
+      const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
+      v[0] *= bf_lo(x.x); v[1] *= bf_hi(x.x); v[2] *= bf_lo(x.y); v[3] *= bf_hi(x.y);
+    }
     if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
       if (p.thr16) {   // same (row, col/8) Philox stream as the in-GEMM epilogue
-        const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+        const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
         const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
         v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
         v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
@@ -474,6 +486,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.thr16 = dropout_thr16(d->p_drop);
   a.inv_keep = a.thr16 ? 1.0f / (1.0f - (float)a.thr16 / 65536.0f) : 1.0f;
   a.seed_lo = (unsigned)d->seed; a.seed_hi = (unsigned)(d->seed >> 32); a.off_lo = (unsigned)d->offset; a.off_hi = (unsigned)(d->offset >> 32);
+  a.rng_state = sam_get_rng_state();
   a.split_k = 1;
   { static int gm = -1; if (gm < 0) { const char* e = getenv("SAM_GEMM_GROUP_M"); gm = e ? atoi(e) : 0; } a.group_m = gm > 0 ? gm : (d->split_k != 0 && d->split_k != 1 ? 1 : 8); }   // measured L2 hit rate: fwd 74% -> 81% with 8; split-K wgrad prefers 1
   a.bias_grad = d->bias_grad;
@@ -481,8 +494,8 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.defer_reduce = d->defer_reduce;
   a.split_used = const_cast<int32_t*>(&d->split_k_used);
   SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
-  if (d->epilogue == SAM_EPI_BIAS_GELU) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
-  if (d->epilogue == SAM_EPI_DGELU) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU needs aux_in");
+  if (d->epilogue == SAM_EPI_BIAS_GELU || d->epilogue == SAM_EPI_BIAS_GELU_GRAD) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
+  if (d->epilogue == SAM_EPI_DGELU || d->epilogue == SAM_EPI_MUL_AUX) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU / MUL_AUX need aux_in");
   if (d->epilogue == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
   int want_split = (d->split_k == 1) ? 0 : d->split_k;
   hipStream_t st = (hipStream_t)stream;
@@ -516,6 +529,8 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
         else if (e2 == SAM_EPI_BIAS) SAM_SPLIT_EPI(SAM_EPI_BIAS, bf16_t);
         else if (e2 == SAM_EPI_BIAS_GELU) SAM_SPLIT_EPI(SAM_EPI_BIAS_GELU, bf16_t);
         else if (e2 == SAM_EPI_DGELU) SAM_SPLIT_EPI(SAM_EPI_DGELU, bf16_t);
+        else if (e2 == SAM_EPI_BIAS_GELU_GRAD) SAM_SPLIT_EPI(SAM_EPI_BIAS_GELU_GRAD, bf16_t);
+        else if (e2 == SAM_EPI_MUL_AUX) SAM_SPLIT_EPI(SAM_EPI_MUL_AUX, bf16_t);
         else if (e2 == SAM_EPI_BIAS_DROPOUT_RES) SAM_SPLIT_EPI(SAM_EPI_BIAS_DROPOUT_RES, bf16_t);
         else { sam_set_error("sam_gemm_bf16: unknown epilogue %d", e2); return SAM_ERR_UNSUPPORTED; }
       }
@@ -536,7 +551,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192 or 1256");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 3192, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192, 1256 or 3192");
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T
@@ -547,12 +562,14 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
       if (e == SAM_EPI_NONE) return launch<true, true, SAM_EPI_NONE, bf16_t>(a, st, want_split, wsb, ft);
       if (e == SAM_EPI_BIAS) return launch<true, true, SAM_EPI_BIAS, bf16_t>(a, st, want_split, wsb, ft);
       if (e == SAM_EPI_BIAS_GELU) return launch<true, true, SAM_EPI_BIAS_GELU, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_BIAS_GELU_GRAD) return launch<true, true, SAM_EPI_BIAS_GELU_GRAD, bf16_t>(a, st, want_split, wsb, ft);
       if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, true, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st, want_split, wsb, ft);
     }
   } else if (lay == 2) {  // dgrad: dy[M,N'] . W[N',K']
     if (!d->c_is_f32) {
       if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, bf16_t>(a, st, want_split, wsb, ft);
       if (e == SAM_EPI_DGELU) return launch<true, false, SAM_EPI_DGELU, bf16_t>(a, st, want_split, wsb, ft);
+      if (e == SAM_EPI_MUL_AUX) return launch<true, false, SAM_EPI_MUL_AUX, bf16_t>(a, st, want_split, wsb, ft);
       if (e == SAM_EPI_BIAS_DROPOUT_RES) return launch<true, false, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, st, want_split, wsb, ft);
     } else if (e == SAM_EPI_NONE) return launch<true, false, SAM_EPI_NONE, float>(a, st, want_split, wsb, ft);
   } else if (lay == 0) {  // wgrad: dy[rows,M]^T . x[rows,N]

@@ -15,6 +15,7 @@
 // SOURCE address (the DMA writes lane-linear).  Both images are bank-conflict free.
 // Measured stand-alone (tools/probes/gemm8_probe.hip, MI355X): 1.36 / 1.51 PFLOP/s at 4096^3 / 8192^3 (256x256), 1.09 PFLOP/s (192x192).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 using namespace samgemm;
 namespace {
@@ -193,7 +194,14 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
       // be covered by one 18-MFMA phase of the partner: two serial epilogues per tile); the lower group drops back behind afterwards.
       if (wr == 0) __builtin_amdgcn_s_barrier();
       const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
-      if constexpr (TM * TN > 18) {     // 32 fragments per wave: two halves, so that the batched operand prefetch of the epilogue fits the register file
+      if (p.dbg == 1) {        // experiment: how long does the tile stream take without any epilogue?  (one dummy store keeps the accumulators live)
+        float sacc = 0.f;
+#pragma unroll
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
+        if (sacc == 12345.678f) reinterpret_cast<bf16_t*>(p.C)[tid] = (bf16_t)1;
+      } else if constexpr (TM * TN > 18) {     // 32 fragments per wave: two halves, so that the batched operand prefetch of the epilogue fits the register file
         gemm_epilogue8<TM, TN, EPI, OutT, 0, RB>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
         gemm_epilogue8<TM, TN, EPI, OutT, RB, TM>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
       } else {
@@ -212,6 +220,306 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
   }
 #undef SAM_DMA_A
 #undef SAM_DMA_B
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Deferred epilogue (192x192 tiles).  With 12 k-tiles per tile (K = 768) an epilogue that runs between two tiles costs a third of the block's
+// life -- the MFMA pipes idle while 36 K outputs per block are converted, activated and stored in one burst, and every CU bursts at the same
+// time (measured: N = 3072, K = 768: 47 us without any epilogue, 61 us with bias, 81 us with bias + GELU + the pre-activation copy).
+// Here a finished tile's accumulators are PARKED in a second register set (72 of the 116 registers the 192x192 configuration leaves free) and
+// the epilogue is cut into 12 slices -- row fragment tm x {column-fragment pair 8-wide, single fragment 4-wide} -- one per phase of the NEXT
+// tile's main loop, executed in the read segment, i.e. underneath the partner wave group's MFMAs.  Slice operands never travel through VGPRs
+// ahead of time: the bias vector sits in LDS for the whole launch, the residual / pre-activation rows of the next slice are DMA-ed into a
+// per-wave LDS slot one phase ahead (same queue and the same counted vmcnt as the operand tiles: nothing drains).
+template <int TM, int TN, int EPI, int TMI, int PART>
+__device__ __forceinline__ void defer_slice(const GemmArgs& p, const f32x4 (&pacc)[TN][TM], int prow0, int pc8, int pc4, bool pfull, const unsigned char* slot,
+                                            const float* bias_lds, int lane, int g, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi) {
+  constexpr int W = PART == 0 ? 8 : 4;
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_BIAS_GELU_GRAD;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_MUL_AUX;
+  const int m = prow0 + 16 * TMI, n = PART == 0 ? pc8 : pc4;
+  float v[W];
+  if constexpr (PART == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(pacc[0][TMI][r]), __float_as_uint(pacc[1][TMI][r]), false, false);
+      v[r] = __uint_as_float(sw[0]);
+      v[4 + r] = __uint_as_float(sw[1]);
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = pacc[2][TMI][r];
+  }
+  const bool ok = pfull || (m < p.M && n < p.N);
+  unsigned pre[W / 2];
+  if (HAS_PRE) {
+    if constexpr (PART == 0) {
+      const uint4 x = *reinterpret_cast<const uint4*>(slot + lane * 16);
+      pre[0] = x.x; pre[1] = x.y; pre[2] = x.z; pre[3] = x.w;
+    } else {
+      const uint2 x = *reinterpret_cast<const uint2*>(slot + lane * 16 + (g & 1) * 8);
+      pre[0] = x.x; pre[1] = x.y;
+    }
+  }
+  if (HAS_BIAS) {
+#pragma unroll
+    for (int q = 0; q < W / 4; ++q) {
+      const float4 b = *reinterpret_cast<const float4*>(bias_lds + n + 4 * q);
+      v[4 * q] += b.x; v[4 * q + 1] += b.y; v[4 * q + 2] += b.z; v[4 * q + 3] += b.w;
+    }
+  }
+  if (EPI == SAM_EPI_BIAS_GELU) {
+    if (ok) {
+      bf16_t* dst = p.aux_out + (int64_t)m * p.ld_aux + n;
+      if constexpr (PART == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+    }
+#pragma unroll
+    for (int r = 0; r < W; ++r) v[r] = gelu_erf(v[r]);
+  }
+  if (EPI == SAM_EPI_BIAS_GELU_GRAD) {
+    float d[W];
+#pragma unroll
+    for (int r = 0; r < W; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
+    if (ok) {
+      bf16_t* dst = p.aux_out + (int64_t)m * p.ld_aux + n;
+      if constexpr (PART == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7]));
+      else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+    }
+  }
+  if (EPI == SAM_EPI_DGELU) {
+#pragma unroll
+    for (int r = 0; r < W / 2; ++r) { v[2 * r] *= gelu_erf_grad(bf_lo(pre[r])); v[2 * r + 1] *= gelu_erf_grad(bf_hi(pre[r])); }
+  }
+  if (EPI == SAM_EPI_MUL_AUX) {
+#pragma unroll
+    for (int r = 0; r < W / 2; ++r) { v[2 * r] *= bf_lo(pre[r]); v[2 * r + 1] *= bf_hi(pre[r]); }
+  }
+  if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
+    if (p.thr16) {      // the (row, col/8) Philox stream of every other epilogue of the family
+      const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+      const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+      for (int r = 0; r < W / 2; ++r) {
+        const unsigned w = PART == 0 ? w4[r] : w4[r + ((n & 4) ? 2 : 0)];
+        v[2 * r] = (w & 0xffffu) >= p.thr16 ? v[2 * r] * p.inv_keep : 0.f;
+        v[2 * r + 1] = (w >> 16) >= p.thr16 ? v[2 * r + 1] * p.inv_keep : 0.f;
+      }
+    }
+    if (p.residual) {
+#pragma unroll
+      for (int r = 0; r < W / 2; ++r) { v[2 * r] += bf_lo(pre[r]); v[2 * r + 1] += bf_hi(pre[r]); }
+    }
+  }
+  if (ok) {
+    bf16_t* dst = reinterpret_cast<bf16_t*>(p.C) + (int64_t)m * p.ldc + n;
+    if constexpr (PART == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]));
+  }
+}
+
+template <bool AKC, bool BKC, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm8d_kernel(GemmArgs p) {
+  constexpr int BM = 192, BN = 192;
+  constexpr int TM = BM / 32, TN = BN / 64, SA = BM / 64, SB = BN / 64, RB = TM / 2, NSL = 2 * TM;
+  constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int BIAS_BYTES = 17408, SLOT_BYTES = 8192;         // bias: N <= 4096 columns + one tile of slack; two residual slots of 1 KB per wave
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_MUL_AUX;
+  static_assert(TN == 3 && SA == SB, "deferred epilogue is laid out for the 192x192 tile");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, g = lane >> 4;
+  const int wr = wave >> 2, wc = wave & 3;
+  const int G = gridDim.x, nblk = p.tiles_m * p.tiles_n;
+  const int my_tiles = (nblk - (int)blockIdx.x + G - 1) / G;
+  const int KT = p.K / BK;
+  const int total = my_tiles * KT;
+  const unsigned kstepA = AKC ? BK * 2 : (unsigned)(BK * p.lda * 2), kstepB = BKC ? BK * 2 : (unsigned)(BK * p.ldb * 2);
+  float* bias_lds = reinterpret_cast<float*>(smem + 2 * STAGE);
+  unsigned char* res_lds = smem + 2 * STAGE + BIAS_BYTES + wave * 1024;
+
+  unsigned offA[SA], offB[SB];
+  int m0, n0, ma, na_, mb_, nb;
+  tile_origin<BM, BN>(p, blockIdx.x, m0, n0);
+  src_offsets<AKC, SA>(offA, p.lda, m0, p.M, wave, lane);
+  src_offsets<BKC, SB>(offB, p.ldb, n0, p.N, wave, lane);
+  int ua = 0, ka = 0, ja = 0, ub = 0, kb = 0, jb = 0;
+  (void)ma; (void)na_; (void)mb_; (void)nb;
+#define SAM_DMA_A()                                                                                                     \
+  do {                                                                                                                  \
+    dma_slices<SA>(p.A, smem + (ua & 1) * STAGE + wave * (SA * 1024), offA, ka * kstepA);                               \
+    ++ua;                                                                                                               \
+    if (++ka == KT) {                                                                                                   \
+      ka = 0; ++ja;                                                                                                     \
+      if (ja < my_tiles) { tile_origin<BM, BN>(p, blockIdx.x + ja * G, ma, na_); src_offsets<AKC, SA>(offA, p.lda, ma, p.M, wave, lane); } \
+    }                                                                                                                   \
+  } while (0)
+#define SAM_DMA_B()                                                                                                     \
+  do {                                                                                                                  \
+    dma_slices<SB>(p.B, smem + (ub & 1) * STAGE + A_BYTES + wave * (SB * 1024), offB, kb * kstepB);                     \
+    ++ub;                                                                                                               \
+    if (++kb == KT) {                                                                                                   \
+      kb = 0; ++jb;                                                                                                     \
+      if (jb < my_tiles) { tile_origin<BM, BN>(p, blockIdx.x + jb * G, mb_, nb); src_offsets<BKC, SB>(offB, p.ldb, nb, p.N, wave, lane); } \
+    }                                                                                                                   \
+  } while (0)
+
+  // the bias vector (zeros when there is none, and behind column N) into LDS, once
+  for (int c4 = tid; c4 * 4 < BIAS_BYTES / 4; c4 += 512) {
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && c4 * 4 < p.N) b = *reinterpret_cast<const float4*>(p.bias + c4 * 4);
+    reinterpret_cast<float4*>(bias_lds)[c4] = b;
+  }
+  unsigned seed_lo = p.seed_lo, seed_hi = p.seed_hi, off_lo = p.off_lo, off_hi = p.off_hi;
+  if (EPI == SAM_EPI_BIAS_DROPOUT_RES) rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
+
+  f32x4 acc[TN][TM], pacc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b) { acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; pacc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  int pslice = NSL, prow0 = 0, pc8 = 0, pc4 = 0;       // parked tile: slices [pslice, NSL) still to do; this lane's first row / pair column / single column
+  bool pfull = true;
+
+  // residual / pre-activation piece of slice s of the parked tile: 16 bytes per lane into this wave's slot (s & 1)
+  const bf16_t* pre_src = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.residual : p.aux_in;
+  const int64_t pre_ld = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.ldr : p.ld_aux;
+#define SAM_RES_DMA(s)                                                                                                                     \
+  do {                                                                                                                                     \
+    if (HAS_PRE && pre_src) {                                                                                                              \
+      const int row_ = min(prow0 + 16 * ((s) >> 1), p.M - 1);                                                                              \
+      const int col_ = min(((s) & 1) ? (pc4 & ~7) : pc8, p.N - 8);                                                                         \
+      const unsigned off_ = (unsigned)(((int64_t)row_ * pre_ld + col_) * 2);                                                               \
+      dma_slices<1>(pre_src, res_lds + ((s) & 1) * SLOT_BYTES, &off_, 0u);                                                                 \
+    }                                                                                                                                      \
+  } while (0)
+#define SAM_SLICE_CASE(S) \
+  case S: defer_slice<TM, TN, EPI, ((S) >> 1), ((S) & 1)>(p, pacc, prow0, pc8, pc4, pfull, res_lds + ((S) & 1) * SLOT_BYTES, bias_lds, lane, g, seed_lo, seed_hi, off_lo, off_hi); break;
+#define SAM_SLICE_CASE2(S) \
+  case S: defer_slice<TM, TN, EPI, ((S) >> 1), 1>(p, pacc, prow0, pc8, pc4, pfull, res_lds + SLOT_BYTES, bias_lds, lane, g, seed_lo, seed_hi, off_lo, off_hi); break;
+#define SAM_RUN_SLICE()                                                                                                                    \
+  do {                                                                                                                                     \
+    switch (pslice) {                                                                                                                      \
+      SAM_SLICE_CASE(0) SAM_SLICE_CASE(1) SAM_SLICE_CASE(2) SAM_SLICE_CASE(3) SAM_SLICE_CASE(4) SAM_SLICE_CASE(5)                          \
+      SAM_SLICE_CASE(6) SAM_SLICE_CASE(7) SAM_SLICE_CASE(8) SAM_SLICE_CASE(9) SAM_SLICE_CASE(10) SAM_SLICE_CASE(11)                        \
+      default: break;                                                                                                                      \
+    }                                                                                                                                      \
+    ++pslice;                                                                                                                              \
+    if (pslice < NSL) SAM_RES_DMA(pslice);                                                                                                 \
+  } while (0)
+
+#define SAM_RUN_PAIR()                                                                                                                     \
+  do {                                                                                                                                     \
+    switch (pslice) {                                                                                                                      \
+      SAM_SLICE_CASE(0) SAM_SLICE_CASE(2) SAM_SLICE_CASE(4) SAM_SLICE_CASE(6) SAM_SLICE_CASE(8) SAM_SLICE_CASE(10)                         \
+      default: break;                                                                                                                      \
+    }                                                                                                                                      \
+    switch (pslice) {                                                                                                                      \
+      SAM_SLICE_CASE2(0) SAM_SLICE_CASE2(2) SAM_SLICE_CASE2(4) SAM_SLICE_CASE2(6) SAM_SLICE_CASE2(8) SAM_SLICE_CASE2(10)                   \
+      default: break;                                                                                                                      \
+    }                                                                                                                                      \
+    pslice += 2;                                                                                                                           \
+    if (pslice < NSL) { SAM_RES_DMA(pslice); SAM_RES_DMA(pslice + 1); }                                                                    \
+  } while (0)
+
+  SAM_DMA_A(); SAM_DMA_B();
+  if (total > 1) { SAM_DMA_B(); vmwait<SB>(); }
+  else vmwait<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // the bias image
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();
+
+  const int sig = ((i >> 3) & 1) | ((g & 1) << 1);
+  bf16x8 af[RB][2], bfr[TN][2];
+  int kt = 0, j = 0;
+  for (int u = 0; u < total; ++u) {
+    const unsigned char* stA = smem + (u & 1) * STAGE;
+    const unsigned char* stB = stA + A_BYTES;
+    // ================= phase 0
+#pragma unroll
+    for (int x = 0; x < TN; ++x)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bfr[x][ks] = frag<BKC>(stB, wc * (BN / 4) + x * 16, ks, i, g, sig);
+#pragma unroll
+    for (int x = 0; x < RB; ++x)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<AKC>(stA, wr * (BM / 2) + x * 16, ks, i, g, sig);
+    if (ua < total) SAM_DMA_A();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int x = 0; x < RB; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[y][ks], af[x][ks], acc[y][x], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= phase 1
+#pragma unroll
+    for (int x = 0; x < RB; ++x)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<AKC>(stA, wr * (BM / 2) + (RB + x) * 16, ks, i, g, sig);
+    if (ub < total) { SAM_DMA_B(); vmwait<SB>(); }          // k-tile u+1 has landed -- and so have the residual pieces queued during k-tile u-1
+    else vmwait<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (pslice < NSL) SAM_RUN_PAIR();                       // two slices of the parked tile's epilogue, underneath the partner group's MFMAs
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int x = 0; x < RB; ++x)
+#pragma unroll
+        for (int y = 0; y < TN; ++y) acc[y][RB + x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[y][ks], af[x][ks], acc[y][RB + x], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    // ================= end of a tile: park the accumulators
+    if (++kt == KT) {
+      while (pslice < NSL) { vmwait<0>(); SAM_RUN_PAIR(); }        // (only when a tile has fewer than 6 k-tiles: the previous one is not finished yet)
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) { pacc[a][b] = acc[a][b]; acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+      pfull = m0 + BM <= p.M && n0 + BN <= p.N;
+      prow0 = m0 + wr * (BM / 2) + i;
+      pc8 = n0 + wc * (BN / 4) + 16 * (g & 1) + 8 * (g >> 1);
+      pc4 = n0 + wc * (BN / 4) + 32 + 4 * g;
+      pslice = p.dbg == 1 ? NSL : 0;
+      if (pslice < NSL) { SAM_RES_DMA(0); SAM_RES_DMA(1); }
+      kt = 0;
+      if (++j < my_tiles) tile_origin<BM, BN>(p, blockIdx.x + j * G, m0, n0);
+    }
+  }
+  while (pslice < NSL) { vmwait<0>(); SAM_RUN_PAIR(); }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+#undef SAM_DMA_A
+#undef SAM_DMA_B
+#undef SAM_RES_DMA
+#undef SAM_SLICE_CASE
+#undef SAM_RUN_SLICE
+#undef SAM_RUN_PAIR
+#undef SAM_SLICE_CASE2
+}
+
+template <bool AKC, bool BKC, int EPI>
+int launch8d(GemmArgs a, int n_cu, hipStream_t st) {
+  constexpr size_t LDS = (size_t)2 * (192 + 192) * 128 + 17408 + 2 * 8192;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8d_kernel<AKC, BKC, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    once = true;
+  }
+  a.tiles_m = (a.M + 191) / 192; a.tiles_n = (a.N + 191) / 192;
+  const int tiles = a.tiles_m * a.tiles_n;
+  gemm8d_kernel<AKC, BKC, EPI><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT>
@@ -246,7 +554,7 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
   }
   int best = -1; float best_score = 0.f;
   for (int c = 0; c < 2; ++c) {
-    if (tile != 0 && tile != 1000 + kCfg[c].bm) continue;
+    if (tile != 0 && tile % 1000 != kCfg[c].bm) continue;        // 1192 / 1256: force the tile; 3192: 192x192 with the deferred epilogue (measured slower)
     const int tiles = ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn);
     const int rounds = (tiles + n_cu - 1) / n_cu;
     const float useful = (float)a.M * (float)a.N / ((float)tiles * kCfg[c].bm * kCfg[c].bn);      // edge tiles compute rows / columns nobody stores
@@ -254,13 +562,23 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     if (best < 0 || score > best_score) { best = c; best_score = score; }
   }
   if (best == 0) return launch8<256, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);
-  if (best == 1) return launch8<192, 192, AKC, BKC, EPI, OutT>(a, n_cu, st);
+  if (best == 1) {
+    // 192x192: the deferred-epilogue kernel whenever its LDS bias image fits and it has something to do per tile
+    static int defer = -1;
+    if (defer < 0) { const char* v = getenv("SAM_GEMM8_DEFER"); defer = v ? atoi(v) : 0; }      // measured slower (see gemm8d_kernel): opt-in
+    if constexpr (std::is_same<OutT, bf16_t>::value) {
+      if ((defer || tile == 3192) && tile != 2192 && a.N <= 4096 && a.M * (int64_t)(EPI == SAM_EPI_BIAS_DROPOUT_RES ? a.ldr : a.ld_aux) * 2 < (int64_t)0x7fffffff) return launch8d<AKC, BKC, EPI>(a, n_cu, st);
+    }
+    return launch8<192, 192, AKC, BKC, EPI, OutT>(a, n_cu, st);
+  }
   return SAM_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-int samgemm::gemm8_launch(const GemmArgs& a, int lay, int e, int c_is_f32, int tile, hipStream_t st) {
+int samgemm::gemm8_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, int tile, hipStream_t st) {
+  GemmArgs a = a_in;
+  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("SAM_GEMM8_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
   // the DMA addresses are 32-bit byte offsets from the operand base; k-tiles are whole; nothing here splits K or reduces a bias gradient
   if (a.K % BK != 0 || a.split_k > 1 || a.bias_grad != nullptr || c_is_f32) return SAM_ERR_UNSUPPORTED;
   const int64_t a_rows = (lay & 2) ? a.M : a.K, b_rows = (lay & 1) ? a.N : a.K;
@@ -269,11 +587,11 @@ int samgemm::gemm8_launch(const GemmArgs& a, int lay, int e, int c_is_f32, int t
   if (lay == 3) {
     if (e == SAM_EPI_NONE) return pick8<true, true, SAM_EPI_NONE, bf16_t>(a, tile, st);
     if (e == SAM_EPI_BIAS) return pick8<true, true, SAM_EPI_BIAS, bf16_t>(a, tile, st);
-    if (e == SAM_EPI_BIAS_GELU) return pick8<true, true, SAM_EPI_BIAS_GELU, bf16_t>(a, tile, st);
+    if (e == SAM_EPI_BIAS_GELU_GRAD) return pick8<true, true, SAM_EPI_BIAS_GELU_GRAD, bf16_t>(a, tile, st);      // (plain BIAS_GELU / DGELU: inference, old callers -> 4-wave kernels)
     if (e == SAM_EPI_BIAS_DROPOUT_RES) return pick8<true, true, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, tile, st);
   } else if (lay == 2) {
     if (e == SAM_EPI_NONE) return pick8<true, false, SAM_EPI_NONE, bf16_t>(a, tile, st);
-    if (e == SAM_EPI_DGELU) return pick8<true, false, SAM_EPI_DGELU, bf16_t>(a, tile, st);
+    if (e == SAM_EPI_MUL_AUX) return pick8<true, false, SAM_EPI_MUL_AUX, bf16_t>(a, tile, st);
     if (e == SAM_EPI_BIAS_DROPOUT_RES) return pick8<true, false, SAM_EPI_BIAS_DROPOUT_RES, bf16_t>(a, tile, st);
   }
   return SAM_ERR_UNSUPPORTED;

@@ -23,12 +23,14 @@ struct GemmArgs {
   int accumulate;
   unsigned thr16; float inv_keep;
   unsigned seed_lo, seed_hi, off_lo, off_hi;
+  const unsigned long long* rng_state;   // device-side {seed, offset base} (hipGraph replays), or NULL
   int tiles_m, tiles_n, group_m;
   int split_k;        // >1: grid = tiles * split_k; split s stores its fp32 partial tile into ws[s] (wgrad: few tiles, very long K)
   float* ws;          // [split_k][M*N] partial outputs, then [split_k][M] partial bias gradients; reduced by splitk_reduce_kernel
   float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
   int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
   int* split_used;    // host pointer: receives the split factor actually launched
+  int dbg;            // tuning experiments only (SAM_GEMM8_DBG): 1 = gemm8 kernels skip the epilogue (results are garbage)
 };
 
 template <typename OutT> struct Store4;
@@ -65,8 +67,10 @@ template <> struct Store4<float> {
 template <int TM, int TN, int EPI, typename OutT, bool FULL, int T0 = 0, int T1 = TM, int N0 = 0, int N1 = TN>
 __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, void* Cout, int64_t ldc, int accumulate, int i, int g) {
   const int n_last = max(p.N - 4, 0), m_last = p.M - 1;
-  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
-  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  unsigned seed_lo = p.seed_lo, seed_hi = p.seed_hi, off_lo = p.off_lo, off_hi = p.off_hi;
+  if (EPI == SAM_EPI_BIAS_DROPOUT_RES) rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_BIAS_GELU_GRAD;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_MUL_AUX;
   float4 b4[TN];
   uint2 pre[HAS_PRE ? TM : 1][HAS_PRE ? TN : 1];   // (only rows [T0, T1) are touched: the rest is never materialised)
   if (HAS_BIAS) {
@@ -77,8 +81,8 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x
     }
   }
   if (HAS_PRE) {
-    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
-    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
+    const bf16_t* src = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.residual : p.aux_in;
+    const int64_t lds_ = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.ldr : p.ld_aux;
 #pragma unroll
     for (int tm = T0; tm < T1; ++tm)
 #pragma unroll
@@ -119,14 +123,25 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
       }
+      if (EPI == SAM_EPI_BIAS_GELU_GRAD) {
+        float d[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
+        if (FULL || (m < p.M && n < p.N))
+          *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+      }
       if (EPI == SAM_EPI_DGELU) {
         const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];
         v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x));
         v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
       }
+      if (EPI == SAM_EPI_MUL_AUX) {
+        const uint2 x = pre[HAS_PRE ? tm : 0][HAS_PRE ? tn : 0];
+        v[0] *= bf_lo(x.x); v[1] *= bf_hi(x.x); v[2] *= bf_lo(x.y); v[3] *= bf_hi(x.y);
+      }
       if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
         if (p.thr16) {
-          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
           const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
           v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
           v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
@@ -156,9 +171,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, const f32x4 (&a
 template <int TM, int TN, int EPI, typename OutT, bool FULL, int T0, int T1>
 __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32x4 (&acc)[TN][TM], int mw, int nw, void* Cout, int64_t ldc, int accumulate, int i, int g) {
   constexpr int NP = TN / 2;
-  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
-  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES;
+  constexpr bool HAS_BIAS = EPI == SAM_EPI_BIAS || EPI == SAM_EPI_BIAS_GELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_BIAS_GELU_GRAD;
+  constexpr bool HAS_PRE = EPI == SAM_EPI_DGELU || EPI == SAM_EPI_BIAS_DROPOUT_RES || EPI == SAM_EPI_MUL_AUX;
   const int n_last = max(p.N - 8, 0), m_last = p.M - 1;
+  unsigned seed_lo = p.seed_lo, seed_hi = p.seed_hi, off_lo = p.off_lo, off_hi = p.off_hi;
+  if (EPI == SAM_EPI_BIAS_DROPOUT_RES) rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
   const int ncol = nw + 16 * (g & 1) + 8 * (g >> 1);
   float4 b4[NP][2];
   uint4 pre[HAS_PRE ? T1 - T0 : 1][HAS_PRE ? NP : 1];
@@ -174,8 +191,8 @@ __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32
     }
   }
   if (HAS_PRE) {
-    const bf16_t* src = EPI == SAM_EPI_DGELU ? p.aux_in : p.residual;
-    const int64_t lds_ = EPI == SAM_EPI_DGELU ? p.ld_aux : p.ldr;
+    const bf16_t* src = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.residual : p.aux_in;
+    const int64_t lds_ = EPI == SAM_EPI_BIAS_DROPOUT_RES ? p.ldr : p.ld_aux;
 #pragma unroll
     for (int tm = T0; tm < T1; ++tm)
 #pragma unroll
@@ -220,6 +237,19 @@ __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = gelu_erf(v[r]);
       }
+      if (EPI == SAM_EPI_BIAS_GELU_GRAD) {
+        float d[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
+        if (ok)
+          *reinterpret_cast<uint4*>(p.aux_out + (int64_t)m * p.ld_aux + n) =
+              make_uint4(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7]));
+      }
+      if (EPI == SAM_EPI_MUL_AUX) {
+        const uint4 x = pre[HAS_PRE ? tm - T0 : 0][HAS_PRE ? q : 0];
+        v[0] *= bf_lo(x.x); v[1] *= bf_hi(x.x); v[2] *= bf_lo(x.y); v[3] *= bf_hi(x.y);
+        v[4] *= bf_lo(x.z); v[5] *= bf_hi(x.z); v[6] *= bf_lo(x.w); v[7] *= bf_hi(x.w);
+      }
       if (EPI == SAM_EPI_DGELU) {
         const uint4 x = pre[HAS_PRE ? tm - T0 : 0][HAS_PRE ? q : 0];
         v[0] *= gelu_erf_grad(bf_lo(x.x)); v[1] *= gelu_erf_grad(bf_hi(x.x)); v[2] *= gelu_erf_grad(bf_lo(x.y)); v[3] *= gelu_erf_grad(bf_hi(x.y));
@@ -227,7 +257,7 @@ __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32
       }
       if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
         if (p.thr16) {
-          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), p.off_lo, p.off_hi, p.seed_lo, p.seed_hi);
+          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
           const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {

@@ -90,7 +90,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, int64_t ldx,
 template <typename InT, int NCH>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
                                                      const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16,
-                                                     float inv_keep, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi, float* ws) {
+                                                     float inv_keep, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi, const unsigned long long* rng_state, float* ws) {
+  if (thr16) rng_resolve(rng_state, seed_lo, seed_hi, off_lo, off_hi);
   constexpr int LN_ROWS = NCH <= 3 ? 3 : (NCH == 4 ? 2 : 1);  // rows a wave keeps in flight (VGPR budget: <= 256 for 2 waves/SIMD)
   __shared__ float red[4][64 * 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -362,8 +363,15 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, 
 }
 
 struct AdamSegs { int64_t end[8]; float lr[8]; int n; };
+// dev_sched (may be NULL): [lr of segment 0..n-1, 1 - beta1^t, 1 - beta2^t] in DEVICE memory -- a captured (hipGraph) launch reads the
+// schedule of the current step from there instead of from its frozen by-value arguments
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, int64_t n, AdamSegs segs, float b1, float b2,
-                                                   float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm) {
+                                                   float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm, const float* dev_sched) {
+  if (dev_sched) {
+    for (int s = 0; s < segs.n; ++s) segs.lr[s] = dev_sched[s];
+    bc1 = dev_sched[segs.n];
+    rsqrt_bc2 = 1.0f / sqrtf(dev_sched[segs.n + 1]);
+  }
   float clip = 1.0f;
   if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));   // torch clip_grad_norm_
   const int64_t n4 = n >> 2;
@@ -450,7 +458,7 @@ template <typename InT>
 int ln_bwd_dispatch(int nch, dim3 grid, hipStream_t st, const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
                     const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16, float inv_keep, uint64_t seed, uint64_t offset, float* ws) {
 #define LN_BWD_CASE(NC) case NC: ln_bwd_kernel<InT, NC><<<grid, dim3(256), 0, st>>>(dy, ldd, x, ldx, mean, rstd, gamma, M, D, dx, dxd, ldo, thr16, inv_keep, \
-      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), ws); break;
+      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), sam_get_rng_state(), ws); break;
   switch (nch) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6) LN_BWD_CASE(7) LN_BWD_CASE(8) default: return SAM_ERR_UNSUPPORTED; }
 #undef LN_BWD_CASE
   return SAM_OK;
@@ -572,23 +580,33 @@ extern "C" int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, v
   return SAM_OK;
 }
 
-extern "C" int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
-                             float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream) {
-  SAM_REQUIRE(p && g && m && v && seg_end && seg_lr, "sam_adam_step: null pointer");
-  SAM_REQUIRE(n > 0 && n % 4 == 0 && nseg >= 1 && nseg <= 8 && step >= 1, "sam_adam_step: need n %% 4 == 0, 1..8 segments, step >= 1");
+static int adam_launch(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg, float beta1,
+                       float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const float* dev_sched, void* stream) {
+  SAM_REQUIRE(p && g && m && v && seg_end && (seg_lr || dev_sched), "sam_adam_step: null pointer");
+  SAM_REQUIRE(n > 0 && n % 4 == 0 && nseg >= 1 && nseg <= 8 && (step >= 1 || dev_sched), "sam_adam_step: need n %% 4 == 0, 1..8 segments, step >= 1");
   AdamSegs segs = {};
   segs.n = nseg;
   for (int s = 0; s < nseg; ++s) {
     SAM_REQUIRE(seg_end[s] % 4 == 0 && (s == 0 || seg_end[s] >= seg_end[s - 1]), "sam_adam_step: segment ends must be ascending multiples of 4");
-    segs.end[s] = seg_end[s]; segs.lr[s] = seg_lr[s];
+    segs.end[s] = seg_end[s]; segs.lr[s] = seg_lr ? seg_lr[s] : 0.f;
   }
   SAM_REQUIRE(seg_end[nseg - 1] == n, "sam_adam_step: last segment must end at n");
-  const float bc1 = 1.0f - powf(beta1, (float)step);
-  const float bc2 = 1.0f - powf(beta2, (float)step);
+  const float bc1 = 1.0f - powf(beta1, (float)(step >= 1 ? step : 1));
+  const float bc2 = 1.0f - powf(beta2, (float)(step >= 1 ? step : 1));
   const int blocks = (int)min((int64_t)4096, ((n >> 2) + 255) / 256);
-  adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, segs, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), gnorm_sq, max_norm);
+  adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, segs, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), gnorm_sq, max_norm,
+                                                                   dev_sched);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
+}
+extern "C" int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                             float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream) {
+  return adam_launch(p, g, m, v, p_bf16, n, seg_end, seg_lr, nseg, beta1, beta2, eps, step, gnorm_sq, max_norm, nullptr, stream);
+}
+extern "C" int sam_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                                 float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, void* stream) {
+  SAM_REQUIRE(dev_sched, "sam_adam_step_dev: null schedule");
+  return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, stream);
 }
 
 extern "C" int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {

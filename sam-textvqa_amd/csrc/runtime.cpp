@@ -1,6 +1,7 @@
 // Host-side runtime bits of libsam_hip.so: error string, version, device query.
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
+#include <atomic>
 #include <stdio.h>
 
 static thread_local char g_err[512] = "";
@@ -17,6 +18,12 @@ extern "C" int sam_abi_version(void) { return 2; }    // 2: sam_bce_loss takes g
 #define SAM_BUILD_DIGEST "unknown"
 #endif
 extern "C" const char* sam_build_digest(void) { return SAM_BUILD_DIGEST; }
+
+// process-wide, not thread-local: PyTorch's autograd engine runs the backward launches (which regenerate the forward's masks) on its own
+// device thread.  One process drives one GPU in this package.
+static std::atomic<const unsigned long long*> g_rng_state{nullptr};
+extern "C" void sam_set_rng_state(const unsigned long long* dev_state) { g_rng_state.store(dev_state); }
+extern "C" const unsigned long long* sam_get_rng_state(void) { return g_rng_state.load(); }
 
 extern "C" int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len) {
   hipDeviceProp_t p;

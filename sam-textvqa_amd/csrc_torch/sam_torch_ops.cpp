@@ -1,0 +1,254 @@
+// PyTorch-ROCm custom ops (namespace sam_hip) over the C ABI of libsam_hip.so.
+//
+// The reference has no operator layer (eager PyTorch inside sam/sa_m4c.py); BASELINE.json's north star asks for the hot path to be "exposed to
+// Python through PyTorch-ROCm custom ops".  This file is that layer: TORCH_LIBRARY schemas + ROCm implementations that check their tensors
+// (TORCH_CHECK -> RuntimeError), allocate outputs through ATen, enqueue on c10::hip::getCurrentHIPStream() and never synchronise.
+// No arithmetic happens here: every op is one or several calls into include/sam_hip.h.
+//   fine-grained ops   sam_hip::linear, spatial_attn_fwd / _bwd, layernorm_fwd / _bwd        (module-level API, tests, external callers)
+//   coarse ops         sam_hip::encoder_layer_fwd / _bwd: one SpatialBertLayer / BertLayer (sam/sa_m4c.py:660-684) = 7 launches forward,
+//                      ~12 backward, enqueued from C++ -- the Python/ctypes route costs ~20 us of host time per launch, 5.7 ms per training
+//                      step against 8 ms of GPU time.
+// Built by sam_textvqa_amd/_build.py with g++ against the torch headers; links libsam_hip.so from its own directory.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "sam_hip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+void* cur_stream() { return (void*)c10::hip::getCurrentHIPStream().stream(); }
+
+void ok(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (rc=", rc, "): ", sam_last_error()); }
+
+const Tensor& need(const Tensor& t, at::ScalarType dt, const char* name) {
+  TORCH_CHECK(t.defined() && t.is_cuda(), name, " must be a GPU tensor (this package has no CPU path)");
+  TORCH_CHECK(t.scalar_type() == dt, name, ": expected dtype ", dt, ", got ", t.scalar_type());
+  return t;
+}
+void need2d(const Tensor& t, const char* name) {
+  need(t, at::kBFloat16, name);
+  TORCH_CHECK(t.dim() == 2 && t.stride(1) == 1, name, ": need a 2-D bf16 tensor with contiguous last dim");
+}
+void* p(const Tensor& t) { return t.defined() ? t.data_ptr() : nullptr; }
+void* p(const optional<Tensor>& t) { return t.has_value() && t->defined() ? t->data_ptr() : nullptr; }
+
+// ---------------------------------------------------------------------------------------------------------------- GEMM (mirror of ops.gemm)
+struct GemmOpt {
+  int epilogue = SAM_EPI_NONE;
+  const Tensor* bias = nullptr;
+  const Tensor* residual = nullptr;
+  const Tensor* aux_in = nullptr;
+  Tensor* aux_out = nullptr;
+  float p_drop = 0.f;
+  int64_t seed = 0, offset = 0;
+  bool out_f32 = false;
+};
+
+Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOpt& o) {
+  need2d(a, "gemm A"); need2d(b, "gemm B");
+  const int64_t M = a_kc ? a.size(0) : a.size(1), K = a_kc ? a.size(1) : a.size(0), N = b_kc ? b.size(0) : b.size(1);
+  Tensor out = at::empty({M, N}, a.options().dtype(o.out_f32 ? at::kFloat : at::kBFloat16));
+  sam_gemm_desc d = {};
+  d.M = (int32_t)M; d.N = (int32_t)N; d.K = (int32_t)K;
+  d.a_kcontig = a_kc; d.b_kcontig = b_kc; d.c_is_f32 = o.out_f32; d.epilogue = o.epilogue;
+  d.A = a.data_ptr(); d.lda = a.stride(0); d.B = b.data_ptr(); d.ldb = b.stride(0); d.C = out.data_ptr(); d.ldc = out.stride(0);
+  d.bias = o.bias ? (const float*)o.bias->data_ptr() : nullptr;
+  if (o.residual) { d.residual = o.residual->data_ptr(); d.ldr = o.residual->stride(0); }
+  if (o.aux_out) { d.aux_out = o.aux_out->data_ptr(); d.ld_aux = o.aux_out->stride(0); }
+  if (o.aux_in) { d.aux_in = o.aux_in->data_ptr(); d.ld_aux = o.aux_in->stride(0); }
+  d.p_drop = o.p_drop; d.seed = (uint64_t)o.seed; d.offset = (uint64_t)o.offset;
+  Tensor ws;
+  if (M <= 4096 && K >= 1536 && M * N <= (4 << 20)) {   // skinny problem with a long K (TextBert's 20 tokens/sample): the library may split K
+    d.split_k = -1;                                      // and fold the epilogue into the partial-sum reduction
+    const int64_t bytes = std::min<int64_t>(8 * (M * N + M) * 4, (int64_t)96 << 20);
+    ws = at::empty({(bytes + 3) / 4}, a.options().dtype(at::kFloat));
+    d.ws = (float*)ws.data_ptr(); d.ws_bytes = ws.numel() * 4; d.defer_reduce = 1;
+  }
+  ok(sam_gemm_bf16(&d, cur_stream()), "sam_gemm_bf16");
+  return out;
+}
+
+// dW += dy^T x (and db += colsum(dy)) for up to 8 jobs in one launch
+struct WgradJob { const Tensor* dy; const Tensor* x; const Tensor* dw; const Tensor* db; };
+void wgrad_grouped(const std::vector<WgradJob>& jobs) {
+  sam_gemm_desc d[8] = {};
+  TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 8, "wgrad_grouped: 1..8 jobs");
+  for (size_t q = 0; q < jobs.size(); ++q) {
+    const WgradJob& j = jobs[q];
+    d[q].M = (int32_t)j.dy->size(1); d[q].N = (int32_t)j.x->size(1); d[q].K = (int32_t)j.dy->size(0);
+    d[q].c_is_f32 = 1; d[q].accumulate = 1; d[q].epilogue = SAM_EPI_NONE;
+    d[q].A = j.dy->data_ptr(); d[q].lda = j.dy->stride(0); d[q].B = j.x->data_ptr(); d[q].ldb = j.x->stride(0);
+    d[q].C = j.dw->data_ptr(); d[q].ldc = j.dw->stride(0);
+    d[q].bias_grad = j.db ? (float*)j.db->data_ptr() : nullptr;
+  }
+  ok(sam_gemm_bf16_grouped(d, (int)jobs.size(), cur_stream()), "sam_gemm_bf16_grouped");
+}
+
+// ---------------------------------------------------------------------------------------------------------------- attention / layernorm
+std::tuple<Tensor, Tensor, Tensor> attn_fwd(const Tensor& qkv, const Tensor& allow, int64_t batch, int64_t heads, double scale, double p_drop, int64_t seed,
+                                            int64_t offset) {
+  need2d(qkv, "qkv"); need(allow, at::kInt, "allow");
+  TORCH_CHECK(allow.dim() == 4 && allow.is_contiguous(), "allow must be a contiguous int32 [B, H|1, N, NW] tensor");
+  const int64_t rows = qkv.size(0), d_model = qkv.size(1) / 3, n = rows / batch;
+  Tensor out = at::empty({rows, d_model}, qkv.options());
+  Tensor lse2 = at::empty({batch, heads, n}, qkv.options().dtype(at::kFloat));
+  Tensor keep = p_drop > 0 ? at::empty({batch, heads, n, allow.size(3)}, allow.options()) : Tensor();
+  ok(sam_attn_fwd(qkv.data_ptr(), (const uint32_t*)allow.data_ptr(), allow.stride(0), allow.size(1) == 1 ? 0 : allow.stride(1), (int)batch, (int)n, (int)heads,
+                  (int)(d_model / heads), (float)scale, (float)p_drop, (uint64_t)seed, (uint64_t)offset, out.data_ptr(), (float*)lse2.data_ptr(),
+                  (uint32_t*)p(keep), cur_stream()),
+     "sam_attn_fwd");
+  return {out, lse2, keep.defined() ? keep : at::empty({0}, allow.options())};
+}
+
+Tensor attn_bwd(const Tensor& dout, const Tensor& qkv, const Tensor& lse2, const Tensor& allow, const Tensor& keep, int64_t batch, int64_t heads, double scale,
+                double p_drop) {
+  need2d(dout, "dout"); need2d(qkv, "qkv"); need(lse2, at::kFloat, "lse2"); need(allow, at::kInt, "allow");
+  const int64_t rows = qkv.size(0), d_model = qkv.size(1) / 3, n = rows / batch;
+  Tensor dqkv = at::empty_like(qkv);
+  Tensor delta = at::empty({batch, heads, n}, lse2.options());
+  const bool has_keep = keep.defined() && keep.numel() > 0;
+  ok(sam_attn_bwd(dout.data_ptr(), qkv.data_ptr(), (const float*)lse2.data_ptr(), (const uint32_t*)allow.data_ptr(), allow.stride(0),
+                  allow.size(1) == 1 ? 0 : allow.stride(1), has_keep ? (const uint32_t*)keep.data_ptr() : nullptr, (int)batch, (int)n, (int)heads,
+                  (int)(d_model / heads), (float)scale, (float)p_drop, dqkv.data_ptr(), (float*)delta.data_ptr(), cur_stream()),
+     "sam_attn_bwd");
+  return dqkv;
+}
+
+std::tuple<Tensor, Tensor, Tensor> ln_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) {
+  TORCH_CHECK(x.is_cuda() && x.dim() == 2 && x.stride(1) == 1 && (x.scalar_type() == at::kBFloat16 || x.scalar_type() == at::kFloat),
+              "layernorm_fwd: need a 2-D bf16/fp32 GPU tensor with contiguous rows");
+  need(gamma, at::kFloat, "gamma"); need(beta, at::kFloat, "beta");
+  const int64_t m = x.size(0), d = x.size(1);
+  Tensor y = at::empty({m, d}, x.options().dtype(at::kBFloat16));
+  Tensor mean = at::empty({m}, x.options().dtype(at::kFloat)), rstd = at::empty({m}, x.options().dtype(at::kFloat));
+  ok(sam_layernorm_fwd(x.data_ptr(), x.scalar_type() == at::kFloat, x.stride(0), (const float*)gamma.data_ptr(), (const float*)beta.data_ptr(), (float)eps, (int)m,
+                       (int)d, y.data_ptr(), y.stride(0), (float*)mean.data_ptr(), (float*)rstd.data_ptr(), cur_stream()),
+     "sam_layernorm_fwd");
+  return {y, mean, rstd};
+}
+
+// -> (dx, dx_dropped or undefined); dgamma / dbeta / dbias accumulated in place
+std::tuple<Tensor, Tensor> ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& mean, const Tensor& rstd, const Tensor& gamma, const Tensor& dgamma,
+                                  const Tensor& dbeta, const Tensor* dbias, bool want_dropped, double p_drop, int64_t seed, int64_t offset) {
+  need2d(dy, "dy");
+  const int64_t m = x.size(0), d = x.size(1);
+  Tensor dx = at::empty({m, d}, dy.options());
+  Tensor dxd = (want_dropped && p_drop > 0) ? at::empty({m, d}, dy.options()) : Tensor();
+  Tensor ws = at::empty({(sam_layernorm_bwd_ws_bytes((int)d) + 3) / 4}, dy.options().dtype(at::kFloat));
+  ok(sam_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.scalar_type() == at::kFloat, x.stride(0), (const float*)mean.data_ptr(),
+                       (const float*)rstd.data_ptr(), (const float*)gamma.data_ptr(), (int)m, (int)d, dx.data_ptr(), p(dxd), dx.stride(0), (float)p_drop,
+                       (uint64_t)seed, (uint64_t)offset, (float*)dgamma.data_ptr(), (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr, 1,
+                       (float*)ws.data_ptr(), cur_stream()),
+     "sam_layernorm_bwd");
+  return {dx, dxd.defined() ? dxd : (want_dropped ? dx : Tensor())};
+}
+
+// ---------------------------------------------------------------------------------------------------------------- coarse: one encoder layer
+// params: wqkv bf16 [3D,D], bqkv f32 [3D], wo bf16 [D,D], bo f32, ln1_w, ln1_b, w1 bf16 [I,D], b1 f32, w2 bf16 [D,I], b2 f32, ln2_w, ln2_b
+enum { P_WQKV, P_BQKV, P_WO, P_BO, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B2, P_LN2W, P_LN2B, P_COUNT };
+// saved: x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2
+enum { S_X, S_QKV, S_CTX, S_LSE, S_KEEP, S_Z1, S_MEAN1, S_RSTD1, S_A, S_PRE, S_H, S_Z2, S_MEAN2, S_RSTD2, S_COUNT };
+
+std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::TensorList params, int64_t batch, int64_t heads, double scale, double p_attn,
+                                      double p_hid, at::IntArrayRef seeds, double eps1, double eps2) {
+  TORCH_CHECK(params.size() == P_COUNT, "encoder_layer_fwd: expected ", (int)P_COUNT, " parameter tensors");
+  TORCH_CHECK(seeds.size() == 6, "encoder_layer_fwd: seeds = (seed, offset) x 3 dropout sites");
+  need2d(x, "x");
+  GemmOpt o;
+  o.epilogue = SAM_EPI_BIAS; o.bias = &params[P_BQKV];
+  Tensor qkv = gemm(x, params[P_WQKV], true, true, o);                                                   // sa_m4c.py:554-560
+  auto [ctx, lse2, keep] = attn_fwd(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]);          // :563-598
+  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_BO]; o.residual = &x; o.p_drop = (float)p_hid; o.seed = seeds[2]; o.offset = seeds[3];
+  Tensor z1 = gemm(ctx, params[P_WO], true, true, o);                                                     // BertSelfOutput via :653
+  auto [a, mean1, rstd1] = ln_fwd(z1, params[P_LN1W], params[P_LN1B], eps1);
+  Tensor pre = at::empty({x.size(0), params[P_W1].size(0)}, x.options());
+  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_GELU_GRAD; o.bias = &params[P_B1]; o.aux_out = &pre;      // pre := gelu'(a W1^T + b1): the backward multiplies, no erf there
+  Tensor h = gemm(a, params[P_W1], true, true, o);                                                        // BertIntermediate via :678
+  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_B2]; o.residual = &a; o.p_drop = (float)p_hid; o.seed = seeds[4]; o.offset = seeds[5];
+  Tensor z2 = gemm(h, params[P_W2], true, true, o);                                                       // BertOutput via :680
+  auto [y, mean2, rstd2] = ln_fwd(z2, params[P_LN2W], params[P_LN2B], eps2);
+  return {y, x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2};
+}
+
+// grads: same order as params, fp32 views into the flat gradient buffer (accumulated in place).  Returns dx (undefined-size-0 when !need_dx).
+Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch, int64_t heads,
+                         double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx) {
+  TORCH_CHECK(saved.size() == S_COUNT && params.size() == P_COUNT && grads.size() == P_COUNT, "encoder_layer_bwd: bad list sizes");
+  Tensor dy = dy_in;
+  if (dy.scalar_type() != at::kBFloat16 || !dy.is_contiguous()) dy = dy.to(at::kBFloat16).contiguous();
+  const Tensor &x = saved[S_X], &qkv = saved[S_QKV], &ctx = saved[S_CTX], &lse2 = saved[S_LSE], &keep = saved[S_KEEP], &z1 = saved[S_Z1], &a = saved[S_A],
+               &pre = saved[S_PRE], &h = saved[S_H], &z2 = saved[S_Z2];
+  // ---- output block: y = LN(dropout(h W2^T + b2) + a)
+  auto [dz2, dy2] = ln_bwd(dy, z2, saved[S_MEAN2], saved[S_RSTD2], params[P_LN2W], grads[P_LN2W], grads[P_LN2B], &grads[P_B2], true, p_hid, seeds[4], seeds[5]);
+  GemmOpt o;
+  o.epilogue = SAM_EPI_MUL_AUX; o.aux_in = &pre;
+  Tensor dpre = gemm(dy2, params[P_W2], true, false, o);
+  // ---- intermediate: h = gelu(a W1^T + b1)
+  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz2;
+  Tensor da = gemm(dpre, params[P_W1], true, false, o);
+  // ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
+  auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3]);
+  Tensor dctx = gemm(dy1, params[P_WO], true, false, GemmOpt());
+  // ---- attention core + fused QKV projection
+  Tensor dqkv = attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
+  const Tensor dw2 = grads[P_W2], dw1 = grads[P_W1], db1 = grads[P_B1], dwo = grads[P_WO], dwqkv = grads[P_WQKV], dbqkv = grads[P_BQKV];
+  wgrad_grouped({{&dy2, &h, &dw2, nullptr}, {&dpre, &a, &dw1, &db1}, {&dy1, &ctx, &dwo, nullptr}, {&dqkv, &x, &dwqkv, &dbqkv}});
+  if (!need_dx) return at::empty({0}, x.options());
+  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz1;
+  return gemm(dqkv, params[P_WQKV], true, false, o);
+}
+
+// ---------------------------------------------------------------------------------------------------------------- fine-grained op wrappers
+std::tuple<Tensor, Tensor> linear_op(const Tensor& x, const Tensor& w, const optional<Tensor>& bias, int64_t epilogue, const optional<Tensor>& residual,
+                                     const optional<Tensor>& aux_in, bool want_aux_out, double p_drop, int64_t seed, int64_t offset, bool b_kcontig, bool out_f32) {
+  GemmOpt o;
+  o.epilogue = (int)epilogue; o.p_drop = (float)p_drop; o.seed = seed; o.offset = offset; o.out_f32 = out_f32;
+  Tensor b_, r_, ai_, aux;
+  if (bias.has_value() && bias->defined()) { b_ = need(*bias, at::kFloat, "bias"); o.bias = &b_; }
+  if (residual.has_value() && residual->defined()) { r_ = *residual; need2d(r_, "residual"); o.residual = &r_; }
+  if (aux_in.has_value() && aux_in->defined()) { ai_ = *aux_in; need2d(ai_, "aux_in"); o.aux_in = &ai_; }
+  const int64_t N = b_kcontig ? w.size(0) : w.size(1);
+  if (want_aux_out) { aux = at::empty({x.size(0), N}, x.options()); o.aux_out = &aux; }
+  Tensor y = gemm(x, w, true, b_kcontig, o);
+  return {y, want_aux_out ? aux : at::empty({0}, x.options())};
+}
+
+std::tuple<Tensor, Tensor, Tensor> layernorm_fwd_op(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps) { return ln_fwd(x, gamma, beta, eps); }
+
+std::tuple<Tensor, Tensor, Tensor> layernorm_bwd_op(const Tensor& dy, const Tensor& x, const Tensor& mean, const Tensor& rstd, const Tensor& gamma) {
+  Tensor dg = at::zeros_like(gamma), db = at::zeros_like(gamma);
+  auto r = ln_bwd(dy, x, mean, rstd, gamma, dg, db, nullptr, false, 0.0, 0, 0);
+  return {std::get<0>(r), dg, db};
+}
+
+}  // namespace
+
+TORCH_LIBRARY(sam_hip, m) {
+  m.def("linear(Tensor x, Tensor w, Tensor? bias, int epilogue, Tensor? residual, Tensor? aux_in, bool want_aux_out, float p_drop, int seed, int offset, "
+        "bool b_kcontig, bool out_f32) -> (Tensor, Tensor)");
+  m.def("spatial_attn_fwd(Tensor qkv, Tensor allow, int batch, int heads, float scale, float p_drop, int seed, int offset) -> (Tensor, Tensor, Tensor)");
+  m.def("spatial_attn_bwd(Tensor dout, Tensor qkv, Tensor lse2, Tensor allow, Tensor keep, int batch, int heads, float scale, float p_drop) -> Tensor");
+  m.def("layernorm_fwd(Tensor x, Tensor gamma, Tensor beta, float eps) -> (Tensor, Tensor, Tensor)");
+  m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor gamma) -> (Tensor, Tensor, Tensor)");
+  m.def("encoder_layer_fwd(Tensor x, Tensor allow, Tensor[] params, int batch, int heads, float scale, float p_attn, float p_hid, int[] seeds, float eps1, "
+        "float eps2) -> Tensor[]");
+  m.def("encoder_layer_bwd(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
+        "float p_hid, int[] seeds, bool need_dx) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under the CUDA dispatch key)
+  m.impl("linear", linear_op);
+  m.impl("spatial_attn_fwd", attn_fwd);
+  m.impl("spatial_attn_bwd", attn_bwd);
+  m.impl("layernorm_fwd", layernorm_fwd_op);
+  m.impl("layernorm_bwd", layernorm_bwd_op);
+  m.impl("encoder_layer_fwd", encoder_layer_fwd);
+  m.impl("encoder_layer_bwd", encoder_layer_bwd);
+}

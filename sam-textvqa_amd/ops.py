@@ -316,6 +316,20 @@ def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm
               float(eps), int(step), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
 
 
+def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
+    """adam_step with the schedule [lr per segment, 1 - beta1^t, 1 - beta2^t] read from the device tensor `dev_sched` (graph-captured steps)"""
+    import ctypes as C
+    n = len(seg_end)
+    ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
+    capi.call("sam_adam_step_dev", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, n, float(betas[0]), float(betas[1]),
+              float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
+
+
+def set_rng_state(state):
+    """state: uint64-as-int64 [2] device tensor {seed, offset base} (or None): see sam_set_rng_state in include/sam_hip.h"""
+    capi.call("sam_set_rng_state", capi.ptr(state))
+
+
 def cast_bf16(x, y):
     capi.call("sam_cast_f32_to_bf16", capi.ptr(x), capi.ptr(y), x.numel(), capi.stream_handle())
     return y

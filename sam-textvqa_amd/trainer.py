@@ -29,7 +29,7 @@ def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, global_count=No
 
 
 class Trainer:
-    def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0):
+    def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0, use_graph=None):
         self.model = model
         self.base_lr = base_lr
         groups = model.get_optimizer_parameters(base_lr)
@@ -58,6 +58,8 @@ class Trainer:
             self._register_regions(reducer)
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
+        self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
+        self._graph, self._graph_sig, self._graph_warm = None, None, False
         dropout_clock.manual_seed((int(seed) ^ (rank << 32)) & 0xFFFFFFFFFFFFFFFF)       # data-parallel replicas draw different masks
 
     # ---- data-parallel layout ------------------------------------------------------------------------------
@@ -144,6 +146,13 @@ class Trainer:
 
     def step(self, batch_dict):
         """one optimisation step; returns the (device, un-synchronised) loss tensor"""
+        if self.use_graph and self.reducer is None:
+            return self._graph_step(batch_dict)
+        return self._eager_step(batch_dict)
+
+    def _eager_step(self, batch_dict, sched_dev=None):
+        """everything one step enqueues.  sched_dev: device tensor [lr per group, 1 - beta1^t, 1 - beta2^t]; given, the optimizer kernel reads the
+        schedule from it (graph capture: by-value arguments would freeze at their capture-time values)"""
         model, flat = self.model, self.flat
         if not model.training:
             model.train()                                        # (recursing over ~160 modules costs 0.6 ms of host time: only when needed)
@@ -171,10 +180,91 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.finish()                               # waits for the overlapped all-reduces
         ops.sumsq(flat.grad, self.gnorm_sq)                    # global norm AFTER the all-reduce, as the reference clips reduced grads
-        ops.adam_step(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self.current_lrs(),
-                      self.global_step + 1, gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps)
-        self.global_step += 1
+        if sched_dev is None:
+            ops.adam_step(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self.current_lrs(),
+                          self.global_step + 1, gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps)
+            self.global_step += 1
+        else:
+            ops.adam_step_dev(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, sched_dev,
+                              gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps)
         return loss.detach()
+
+    # ---- the step as ONE hipGraph ---------------------------------------------------------------------------
+    # ~280 launches per step cost the host 4.7 ms (Python modules, autograd nodes, dispatcher) however they are issued; the step's shapes are
+    # static, so it is captured once and replayed: the host then spends ~0.2 ms per step (input copies + one graph launch).  What varies from
+    # step to step lives in device memory: the dropout state (sam_set_rng_state: captured launches add a per-replay offset base to their
+    # by-value offsets; the graph's first node advances it) and the optimizer schedule (sam_adam_step_dev).
+    GRAPH_OFFSET_STRIDE = 1 << 20          # dropout offsets consumed per step (far above the ~40 sites of a step)
+
+    def _flatten(self, bd):
+        out = []
+        for k in sorted(bd):
+            v = bd[k]
+            if torch.is_tensor(v):
+                out.append((k, None, v))
+            elif isinstance(v, dict):
+                out.extend((k, kk, vv) for kk, vv in sorted(v.items()) if torch.is_tensor(vv))
+        return out
+
+    def _graph_step(self, batch_dict):
+        dev = self.flat.flat.device
+        items = self._flatten(batch_dict)
+        sig = tuple((k, kk, tuple(v.shape), v.dtype) for k, kk, v in items)
+        if self._graph is not None and sig != self._graph_sig:
+            return self._eager_step(batch_dict)                  # another shape (last partial batch): eager, the graph stays valid for the usual one
+        if self._graph is None:
+            if not self._graph_warm:                             # first call: a normal eager step (lazy kernel attributes, workspaces, RCCL-free init)
+                self._graph_warm = True
+                return self._eager_step(batch_dict)
+            try:
+                self._capture(items, sig, dev)
+            except Exception as e:                               # capture is an optimisation: never lose the run over it
+                import logging
+                logging.getLogger(__name__).warning("hipGraph capture of the training step failed (%s: %s); continuing eagerly", type(e).__name__, e)
+                ops.set_rng_state(None)
+                self.use_graph, self._graph = False, None
+                return self._eager_step(batch_dict)
+        for (k, kk, v), dst in zip(items, self._static_in):
+            if v.data_ptr() != dst.data_ptr():
+                dst.copy_(v, non_blocking=True)
+        lrs = self.current_lrs()
+        t = self.global_step + 1
+        host = self._sched_host
+        for i, lr in enumerate(lrs):
+            host[i] = lr
+        host[len(lrs)] = 1.0 - self.betas[0] ** t
+        host[len(lrs) + 1] = 1.0 - self.betas[1] ** t
+        self._sched_dev.copy_(host, non_blocking=True)
+        self._graph.replay()
+        self.global_step += 1
+        return self._static_loss
+
+    def _capture(self, items, sig, dev):
+        static_in = [torch.empty_like(v, device=dev).copy_(v) for _, _, v in items]
+        static_bd = {}
+        for (k, kk, _), t in zip(items, static_in):
+            if kk is None:
+                static_bd[k] = t
+            else:
+                static_bd.setdefault(k, {})[kk] = t
+        n = len(self.group_lr)
+        self._sched_host = torch.zeros(n + 2, dtype=torch.float32).pin_memory()
+        self._sched_dev = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self._rng_state = torch.tensor([dropout_clock.seed & 0x7FFFFFFFFFFFFFFF, dropout_clock.offset + self.GRAPH_OFFSET_STRIDE], dtype=torch.int64, device=dev)
+        saved_offset, dropout_clock.offset = dropout_clock.offset, 0          # by-value offsets inside the graph: 1, 2, 3, ... per site
+        g = torch.cuda.CUDAGraph()
+        torch.cuda.synchronize()
+        ops.set_rng_state(self._rng_state)
+        try:
+            with torch.cuda.graph(g):
+                self._rng_state[1:2].add_(self.GRAPH_OFFSET_STRIDE)           # first node: fresh masks for this replay
+                bd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in static_bd.items()}
+                loss = self._eager_step(bd, sched_dev=self._sched_dev)
+                self._static_loss = loss
+        finally:
+            ops.set_rng_state(None)                                           # the captured launches keep the pointer; eager launches go back to by-value
+            dropout_clock.offset = saved_offset
+        self._graph, self._graph_sig, self._static_in = g, sig, static_in
 
     # ---- checkpoint in the reference's layout (train.py:177-187) ------------------------------------------
     def _torch_optimizer(self, with_state):

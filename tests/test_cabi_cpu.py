@@ -103,3 +103,16 @@ def test_a_library_built_from_other_sources_is_refused(tmp_path, monkeypatch):
     monkeypatch.setattr(b, "build", lambda *a, **k: (_ for _ in ()).throw(RuntimeError("hipcc failed on gemm.hip")))
     with pytest.raises(_capi.SamHipError, match="could not be"):
         _capi.lib()                                                        # a failed rebuild is an error even though an older .so exists
+
+
+def test_torch_custom_ops_build_and_register_without_a_gpu():
+    """csrc_torch/sam_torch_ops.cpp: TORCH_LIBRARY(sam_hip) schemas are visible to the dispatcher after load; running them needs the GPU"""
+    from sam_textvqa_amd import torchops
+    ns = torchops.ns()
+    for op in ("linear", "spatial_attn_fwd", "spatial_attn_bwd", "layernorm_fwd", "layernorm_bwd", "encoder_layer_fwd", "encoder_layer_bwd"):
+        assert hasattr(ns, op), op
+    schema = str(torch.ops.sam_hip.encoder_layer_fwd.default._schema)
+    assert "Tensor[] params" in schema and "int[] seeds" in schema
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, NotImplementedError)):
+            torch.ops.sam_hip.layernorm_fwd(torch.zeros(4, 8), torch.ones(8), torch.zeros(8), 1e-12)       # no CPU kernel is registered

@@ -24,6 +24,10 @@ def gelu(x):
     return 0.5 * x * (1 + torch.erf(x / math.sqrt(2)))
 
 
+def dgelu(x):
+    return 0.5 * (1 + torch.erf(x / math.sqrt(2))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
 SHAPES = [(728, 768, 768), (256, 128, 64), (130, 5000, 768), (200, 768, 3008), (1000, 2304, 768), (48, 768, 8), (1, 8, 8)]
 
 
@@ -51,6 +55,16 @@ def test_forward_gelu_and_dropout_residual():
     h = ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS_GELU, bias=b.cuda(), aux_out=pre)
     assert_close_bf16(pre, pre_ref, name="pre-gelu")
     assert_close_bf16(h, gelu(pre_ref), name="gelu")
+    # training form: the derivative is stored instead of the pre-activation (4-wave kernels via force_tile, 8-wave by default) ...
+    for ft in (128, 0):
+        dact = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        h2 = ops.gemm(x.cuda(), w.cuda(), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=b.cuda(), aux_out=dact, force_tile=ft)
+        assert_close_bf16(dact, dgelu(pre_ref), name="gelu'")
+        assert_close_bf16(h2, gelu(pre_ref), name="gelu (training form)")
+        # ... and the backward multiplies by it
+        dyy, wt = rnd((M, K), 44), rnd((K, N), 45, 0.05)
+        got = ops.gemm(dyy.cuda(), wt.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=dact, force_tile=ft)
+        assert_close_bf16(got, (dyy.float() @ wt.float()) * dact.float().cpu(), name="dgrad * gelu'")
     # dense -> (+bias) -> dropout(p=0) -> + residual
     w2, res = rnd((K, N), 7, 0.03), rnd((M, K), 8)
     b2 = torch.randn(K, generator=torch.Generator().manual_seed(9)) * 0.1
@@ -178,8 +192,8 @@ def test_both_tile_configs_all_layouts(tile):
     assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
 
 
-@pytest.mark.parametrize("tile", [1192, 1256])
-@pytest.mark.parametrize("M,N,K", [(3500, 3080, 128), (600, 520, 64), (4000, 2304, 192), (256, 256, 704)])
+@pytest.mark.parametrize("tile", [1192, 3192, 1256])      # 3192: 192x192 with the deferred (sliced, LDS-staged) epilogue (opt-in: measured slower)
+@pytest.mark.parametrize("M,N,K", [(3500, 3080, 128), (600, 520, 64), (4000, 2304, 192), (256, 256, 704), (11648, 768, 768)])
 def test_eight_wave_persistent_kernels(tile, M, N, K):
     """gemm8.hip (256x256 / 192x192 tiles, one block per CU walking several tiles): ragged M and N, one to eleven k-tiles per tile, more tiles
     than CUs (so blocks cross tile boundaries with operands of the next tile in flight), forward and dgrad layouts, every fused epilogue"""
@@ -191,8 +205,8 @@ def test_eight_wave_persistent_kernels(tile, M, N, K):
     assert_close_bf16(ops.gemm(xg, wg, force_tile=tile), ref, name="fwd none")
     assert_close_bf16(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ref + b, name="fwd bias")
     pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
-    h = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_GELU, bias=bg, aux_out=pre, force_tile=tile)
-    assert_close_bf16(pre, ref + b, name="fwd pre-gelu")
+    h = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_GELU_GRAD, bias=bg, aux_out=pre, force_tile=tile)
+    assert_close_bf16(pre, dgelu(ref + b), name="fwd gelu'")
     assert_close_bf16(h, gelu(ref + b), name="fwd gelu")
     res = rnd((M, N), 64)
     z = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), force_tile=tile)
@@ -206,9 +220,7 @@ def test_eight_wave_persistent_kernels(tile, M, N, K):
     refd = x.float() @ wT.float()
     assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, force_tile=tile), refd, name="dgrad none")
     prev = rnd((M, N), 66)
-    xp = prev.float()
-    dg = 0.5 * (1 + torch.erf(xp / math.sqrt(2))) + xp * torch.exp(-0.5 * xp * xp) / math.sqrt(2 * math.pi)
-    assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_DGELU, aux_in=prev.cuda(), force_tile=tile), refd * dg, name="dgrad dgelu")
+    assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=prev.cuda(), force_tile=tile), refd * prev.float(), name="dgrad * aux")
     assert_close_bf16(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=res.cuda(), force_tile=tile), refd + res.float(), name="dgrad+res")
     # strided operand views (leading dimensions larger than the logical width), as the attention block hands them over
     big = rnd((M, K + 64), 67).cuda()

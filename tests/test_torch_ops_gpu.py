@@ -1,0 +1,172 @@
+"""GPU: the PyTorch-ROCm custom-op layer (torch.ops.sam_hip.*, csrc_torch/sam_torch_ops.cpp) -- fine-grained ops against fp32 references,
+and the coarse per-layer ops against the per-kernel ctypes route (same kernels in the same order: bit-identical)."""
+import math
+
+import pytest
+import torch
+
+from tests.util import assert_close_bf16
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(torch.bfloat16)
+
+
+def test_fine_grained_ops_through_torch_ops():
+    from sam_textvqa_amd import _capi as capi, ops, torchops
+    ns = torchops.ns()
+    x, w = rnd((728, 768), 1), rnd((3072, 768), 2, 0.05)
+    b = torch.randn(3072, generator=torch.Generator().manual_seed(3)) * 0.1
+    y, aux = torch.ops.sam_hip.linear(x.cuda(), w.cuda(), b.cuda(), capi.EPI_BIAS_GELU, None, None, True, 0.0, 0, 0, True, False)
+    pre = x.float() @ w.float().t() + b
+    assert_close_bf16(aux, pre, name="pre-activation")
+    assert_close_bf16(y, 0.5 * pre * (1 + torch.erf(pre / math.sqrt(2))), name="gelu")
+    # dgrad layout + residual through the same op
+    wT, res = rnd((768, 3072), 4, 0.05), rnd((728, 3072), 5)
+    z, none = ns.linear(x.cuda(), wT.cuda(), None, capi.EPI_BIAS_DROPOUT_RES, res.cuda(), None, False, 0.0, 0, 0, False, False)
+    assert none.numel() == 0
+    assert_close_bf16(z, x.float() @ wT.float() + res.float(), name="dgrad+res")
+    # layernorm fwd / bwd
+    g, be = torch.rand(768) + 0.5, torch.randn(768) * 0.1
+    xf = rnd((300, 768), 6)
+    yl, mean, rstd = ns.layernorm_fwd(xf.cuda(), g.cuda(), be.cuda(), 1e-12)
+    xr = xf.float().requires_grad_(True)
+    mu = xr.mean(-1, keepdim=True)
+    ref = (xr - mu) / torch.sqrt(((xr - mu) ** 2).mean(-1, keepdim=True) + 1e-12) * g + be
+    assert_close_bf16(yl, ref.detach(), name="ln fwd")
+    dy = rnd((300, 768), 7)
+    ref.backward(dy.float())
+    dx, dg, db = ns.layernorm_bwd(dy.cuda(), xf.cuda(), mean, rstd, g.cuda())
+    assert_close_bf16(dx, xr.grad, name="ln bwd dx")
+    assert_close_bf16(db, dy.float().sum(0), ulps=0, name="ln bwd dbeta")
+    # fused attention: equals the ctypes route bit for bit (same entry point underneath)
+    B, N, H = 3, 182, 12
+    qkv = rnd((B * N, 3 * 768), 8).cuda()
+    kv = torch.ones(B, N - 12, dtype=torch.uint8); kv[1, 100:] = 0
+    allow = ops.mask_bits_prefix_lm(kv.cuda(), 12)
+    o1, l1, k1 = ns.spatial_attn_fwd(qkv, allow, B, H, 0.125, 0.1, 5, 9)
+    o2, l2, k2 = ops.attn_fwd(qkv, allow, B, H, 0.125, 0.1, 5, 9)
+    assert torch.equal(o1, o2) and torch.equal(l1, l2) and torch.equal(k1, k2)
+    do = rnd((B * N, 768), 9).cuda()
+    assert torch.equal(ns.spatial_attn_bwd(do, qkv, l1, allow, k1, B, H, 0.125, 0.1), ops.attn_bwd(do, qkv, l2, allow, k2, B, H, 0.125, 0.1))
+    # argument errors surface as RuntimeError, not as a crash
+    with pytest.raises(RuntimeError):
+        ns.layernorm_fwd(xf, g.cuda(), be.cuda(), 1e-12)          # CPU tensor
+    with pytest.raises(RuntimeError):
+        ns.linear(x.cuda()[:, :100], w.cuda(), None, 0, None, None, False, 0.0, 0, 0, True, False)        # K mismatch / K % 8
+
+
+@pytest.mark.parametrize("kind", ["s", "n"])
+def test_coarse_encoder_layer_ops_equal_the_per_kernel_route(kind, monkeypatch):
+    """EncoderLayerFn through torch.ops.sam_hip.encoder_layer_fwd/_bwd vs through ~35 ctypes launches: outputs, input gradient and every
+    parameter gradient bit-identical, dropout on (same counter-based seeds)"""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd import torchops
+    from sam_textvqa_amd.autograd import dropout_clock
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import make_batch, mmt_config_dict
+    torch.manual_seed(0)
+    cfg = M.BertConfig.from_dict(mmt_config_dict(3, (kind,)))
+    layer = (M.SpatialBertLayer if kind == "s" else M.BertLayer)(cfg).cuda().train()
+    fp = prepare(layer)
+    B, N = 4, 182
+    bd = make_batch(B, vocab=100, device="cuda", seed=4)
+    x = torch.randn(B, N, 768, device="cuda").to(torch.bfloat16)
+    key_valid = torch.cat([bd["question_mask"], bd["pad_obj_mask"], bd["pad_ocr_mask"]], 1)
+    allow = M.AllowBits(M.ops.mask_bits_prefix_lm(key_valid.to(torch.uint8).contiguous(), 12))
+    gout = torch.randn(B, N, 768, device="cuda")
+    res = []
+    for coarse in (True, False):
+        monkeypatch.setattr(torchops, "enabled", lambda c=coarse: c)
+        dropout_clock.manual_seed(77)
+        fp.zero_grad()
+        xi = x.clone().requires_grad_(True)
+        y = layer(xi, allow, bd["spatial_adj_matrices"]["3"])[0] if kind == "s" else layer(xi, allow)[0]
+        (y.float() * gout).sum().backward()
+        res.append((y.detach().clone(), xi.grad.clone(), fp.grad.clone()))
+    (y1, dx1, g1), (y0, dx0, g0) = res
+    assert torch.equal(y1, y0) and torch.equal(dx1, dx0) and torch.equal(g1, g0)
+    assert g1.abs().sum().item() > 0 and dx1.abs().sum().item() > 0
+
+
+def test_device_side_rng_state_equals_by_value_offsets():
+    """sam_set_rng_state: a launch with by-value (seed, offset) under the device state {S, base} draws the masks of the by-value pair
+    (S, base + offset) -- forward GEMM epilogue (4-wave and 8-wave kernels), LayerNorm backward (which regenerates that mask), fused attention,
+    previous-prediction gather.  This is what lets a captured hipGraph draw fresh, forward/backward-consistent masks on every replay."""
+    from sam_textvqa_amd import _capi as capi, ops
+    S, base, off = 0x1234567, 5 << 20, 7
+    state = torch.tensor([S, base], dtype=torch.int64, device="cuda")
+    x, w, res = rnd((1000, 768), 1).cuda(), rnd((768, 768), 2, 0.05).cuda(), rnd((1000, 768), 3).cuda()
+    b = torch.randn(768, device="cuda")
+    for tile in (128, 1192):
+        want = ops.gemm(x, w, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b, residual=res, p_drop=0.1, seed=S, offset=base + off, force_tile=tile)
+        ops.set_rng_state(state)
+        try:
+            got = ops.gemm(x, w, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b, residual=res, p_drop=0.1, seed=999, offset=off, force_tile=tile)
+        finally:
+            ops.set_rng_state(None)
+        assert torch.equal(got, want)
+        other = ops.gemm(x, w, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=b, residual=res, p_drop=0.1, seed=999, offset=off, force_tile=tile)
+        assert not torch.equal(other, want)                     # back to by-value
+    # LayerNorm backward's dropped gradient uses the same stream
+    dy, z = rnd((1000, 768), 4).cuda(), rnd((1000, 768), 5).cuda()
+    g = torch.ones(768, device="cuda")
+    _, mean, rstd = ops.layernorm_fwd(z, g, torch.zeros(768, device="cuda"), 1e-12)
+    dg, db = torch.zeros(768, device="cuda"), torch.zeros(768, device="cuda")
+    _, want = ops.layernorm_bwd(dy, z, mean, rstd, g, dg, db, want_dropped=True, p_drop=0.1, seed=S, offset=base + off)
+    ops.set_rng_state(state)
+    try:
+        _, got = ops.layernorm_bwd(dy, z, mean, rstd, g, dg, db, want_dropped=True, p_drop=0.1, seed=999, offset=off)
+        B, N, H = 2, 182, 12
+        qkv = rnd((B * N, 3 * 768), 8).cuda()
+        allow = ops.mask_bits_prefix_lm(torch.ones(B, N - 12, dtype=torch.uint8, device="cuda"), 12)
+        _, _, keep_got = ops.attn_fwd(qkv, allow, B, H, 0.125, 0.1, 999, off)
+    finally:
+        ops.set_rng_state(None)
+    assert torch.equal(got, want)
+    _, _, keep_want = ops.attn_fwd(qkv, allow, B, H, 0.125, 0.1, S, base + off)
+    assert torch.equal(keep_got, keep_want)
+
+
+def test_training_step_captured_as_a_hipgraph():
+    """Trainer(use_graph=True): the step is captured once and replayed.  Dropout off: the replayed trajectory equals the eager one (same
+    kernels, learning-rate schedule and Adam bias corrections read from device memory); dropout on: every replay draws new masks."""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    from tests.test_model_gpu import _small_full_model
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    runs = []
+    for use_graph in (False, True):
+        model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+        tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=use_graph, schedule=dict(warmup_iters=4))      # LR changes every step
+        losses = [tr.step(clone_batch(batch)).item() for _ in range(7)]
+        assert (tr._graph is not None) == use_graph and tr.global_step == 7
+        runs.append((losses, tr.flat.flat.clone(), tr.exp_avg_sq.clone()))
+    (l0, p0, v0), (l1, p1, v1) = runs
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)      # (two scatter kernels use fp32 atomics: not bit-reproducible)
+    assert (p0 - p1).abs().max().item() < 5e-3 and l1[-1] < 0.7 * l1[0]        # 7 Adam steps at lr 1e-3: a parameter moves <= 7e-3 in total
+    # a batch of another shape falls back to the eager path without disturbing the graph
+    small = make_batch(2, vocab=300, device="cuda", seed=5)
+    small["question_indices"] = small["question_indices"] % 500
+    assert torch.isfinite(tr.step(clone_batch(small))) and tr.global_step == 8
+    assert torch.isfinite(tr.step(clone_batch(batch))) and tr.global_step == 9
+    # dropout on: same batch, consecutive replays -> different masks -> different losses; and the loss still goes down
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import mmt_config_dict, text_bert_config_dict
+    torch.manual_seed(1)
+    model = M.SAM4C(M.BertConfig.from_dict(mmt_config_dict(3, ("n", "s"))), M.BertConfig.from_dict(dict(text_bert_config_dict(), num_hidden_layers=1, vocab_size=500)),
+                    num_answers=300, bos_idx=1)
+    tr = Trainer(model, base_lr=2e-4, seed=3, use_graph=True)
+    before = tr.flat.flat.clone()
+    tr.step(clone_batch(batch)); tr.step(clone_batch(batch))
+    frozen = tr.flat.flat.clone()
+    a = tr.step(clone_batch(batch)).item()
+    tr.flat.flat.copy_(frozen); tr.flat.refresh_shadows()          # same weights, same batch, next replay: only the masks differ
+    b = tr.step(clone_batch(batch)).item()
+    assert tr._graph is not None and a != b and abs(a - b) < 0.2 * abs(a), (a, b)
+    ls = [tr.step(clone_batch(batch)).item() for _ in range(30)]
+    assert ls[-1] < 0.8 * ls[0] and not torch.equal(before, tr.flat.flat)
