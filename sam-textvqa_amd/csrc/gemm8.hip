@@ -222,6 +222,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
 #undef SAM_DMA_B
 }
 
+// (Measured and not kept -- a three-stage ring for the 192x192 tile (3 x 48 KB) that fetches two k-tiles ahead and issues the DMA slices between
+// MFMA groups inside the MFMA segment, so that the read segment holds fragment reads only: 58.0 vs 50.5 us at 11648 x 768 x 3072, 69.9 vs 60.3 us
+// at N = 3072 / K = 768.  Splitting the MFMA stream around the DMA issue costs more than the shorter read segment returns.)
 // ---------------------------------------------------------------------------------------------------------------------------------
 // Deferred epilogue (192x192 tiles).  With 12 k-tiles per tile (K = 768) an epilogue that runs between two tiles costs a third of the block's
 // life -- the MFMA pipes idle while 36 K outputs per block are converted, activated and stored in one burst, and every CU bursts at the same
