@@ -137,7 +137,7 @@ def roofline_from(agg):
     return roof, table[:12], extra
 
 
-def cpu_baseline(context, layers, vocab, budget_s=25.0):
+def cpu_baseline(context, layers, vocab, budget_s=60.0, warmup=5, timed=10):
     """the fp32 oracle (a port of the reference, proved equal to it by tests/golden) timed on this host: config 1 of
     BASELINE.json (B=4).  `faithful` keeps the reference's per-layer mask rebuild and debug torch.unique."""
     from oracle import sa_m4c_oracle as O
@@ -148,34 +148,78 @@ def cpu_baseline(context, layers, vocab, budget_s=25.0):
     model = O.SAM4C(O.BertConfig.from_dict(S.mmt_config_dict(context, layers)), O.BertConfig.from_dict(S.text_bert_config_dict()), num_answers=vocab)
     opt, sched = O.make_optimizer(model)
     batch = S.make_batch(4, vocab=vocab, context=context, device="cpu", seed=99)
-    out = {}
+    out, n_timed = {}, {}
     for mode in ("faithful", "clean"):
         O.SpatialBertSelfAttention.faithful = mode == "faithful"
         model.train()
-        times = []
         t_end = time.time() + budget_s / 2
-        while len(times) < 4 and (time.time() < t_end or len(times) < 2):
+        for _ in range(warmup):
+            O.train_step(model, S.clone_batch(batch), opt, sched)
+        times = []
+        while len(times) < timed and (time.time() < t_end or len(times) < 3):
             t0 = time.time()
             O.train_step(model, S.clone_batch(batch), opt, sched)
             times.append(time.time() - t0)
-        out[mode] = 4.0 / statistics.median(times[1:] if len(times) > 1 else times)
+        out[mode], n_timed[mode] = 4.0 / statistics.median(times), len(times)
     O.SpatialBertSelfAttention.faithful = False
     return dict(value=round(out["faithful"], 3), unit="samples/s", cores=threads, kind="port",
-                sample="oracle SAM4C (fp32, torch CPU) full train step, c3 shapes, B=4, median of %d steps after 1 warm-up; 'faithful' variant (reference's per-layer mask rebuild + debug torch.unique)" % 3,
+                sample="oracle SAM4C (fp32, torch CPU, %d threads) full train step, c3 shapes, B=4 (BASELINE config 1), median of %d steps after %d warm-up; "
+                       "'faithful' variant (reference's per-layer mask rebuild + debug torch.unique)" % (threads, n_timed["faithful"], warmup),
                 clean_variant_samples_per_s=round(out["clean"], 3))
+
+
+def eager_rocm_baseline(context, layers, vocab, shape, batch_size, dev, steps=8, warmup=3):
+    """BASELINE.json config 2's A/B partner: the reference's algorithm as eager PyTorch-ROCm on THIS GPU -- the fp32 oracle (a port proved equal to the
+    reference by tests/golden) moved to the device, same shapes and batch as the timed run; fp32 and bf16-autocast, faithful and clean variants.
+    Runs after the timed region; the product path never touches it."""
+    from oracle import sa_m4c_oracle as O
+    from sam_textvqa_amd import synthetic as S
+    res = {}
+    torch.manual_seed(0)
+    T, n_obj, n_ocr, n_dec = shape
+    model = O.SAM4C(O.BertConfig.from_dict(S.mmt_config_dict(context, layers, n_dec=n_dec, T=T, n_obj=n_obj, n_ocr=n_ocr)),
+                    O.BertConfig.from_dict(S.text_bert_config_dict()), num_answers=vocab).to(dev)
+    opt, sched = O.make_optimizer(model)
+    batch = S.make_batch(batch_size, *shape, vocab=vocab, context=context, device=dev, seed=99)
+    for name, faithful, autocast in (("fp32_faithful", True, False), ("fp32_clean", False, False), ("bf16_autocast_clean", False, True)):
+        O.SpatialBertSelfAttention.faithful = faithful
+        model.train()
+        try:
+            def one():
+                if autocast:
+                    with torch.autocast("cuda", dtype=torch.bfloat16):
+                        O.train_step(model, S.clone_batch(batch), opt, sched)
+                else:
+                    O.train_step(model, S.clone_batch(batch), opt, sched)
+            for _ in range(warmup):
+                one()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                one()
+            torch.cuda.synchronize()
+            res[name] = round(batch_size * steps / (time.perf_counter() - t0), 1)
+        except Exception as e:          # (e.g. an op without a bf16 kernel): report, do not lose the bench line
+            res[name] = "failed: %s" % (str(e)[:120],)
+    O.SpatialBertSelfAttention.faithful = False
+    del model, opt
+    torch.cuda.empty_cache()
+    return dict(unit="samples/s", batch=batch_size, steps=steps, warmup=warmup, kind="port (oracle on the device, eager PyTorch-ROCm)", **res)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch (weak scaling)")
     ap.add_argument("--context", type=int, default=3)
     ap.add_argument("--vocab", type=int, default=5000)
     ap.add_argument("--shape", default="c3", choices=["c3", "stress"],
                     help="c3: T=20,100 obj,50 OCR,12 dec, layers n,n,s,s,s,s (BASELINE configs 1-4); stress: 200 obj,100 OCR,30 dec, 12 layers (config 5)")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step from Python instead of replaying the captured hipGraph (1 GPU only; N > 1 is always eager)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: all-reduce the gradient buckets after the backward pass instead of underneath it (A/B of the overlap)")
+    ap.add_argument("--no-eager-baseline", action="store_true", help="skip the eager PyTorch-ROCm leg (the oracle on the GPU, BASELINE config 2's A/B partner)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -191,7 +235,14 @@ def main():
     shape = SHAPES[args.shape]
     layers = ("n", "n", "s", "s", "s", "s") if args.shape == "c3" else ("n", "n") + ("s",) * 10
     model = build_model(args.context, layers, args.vocab, shape)
-    trainer = Trainer(model, seed=1234 + rank, use_graph=(world == 1 and not args.no_graph))
+    reducer = None
+    if world > 1 and args.no_overlap:
+        from sam_textvqa_amd.params import prepare
+        groups = model.get_optimizer_parameters(1e-4)
+        flat = prepare(model, groups=[g["params"] for g in groups])
+        reducer = parallel.GradReducer(flat.grad, overlap=False)
+    trainer = Trainer(model, seed=1234 + rank, use_graph=(world == 1 and not args.no_graph), reducer=reducer)
+    trainer.measure_comm = world > 1
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
 
     for _ in range(args.warmup):
@@ -218,6 +269,7 @@ def main():
         parallel.dist.destroy_process_group()
         return
     gb = args.batch * world
+    trainer.measure_comm = False
     res = {
         "metric": "training samples/sec, SA-M4C c=%d synthetic batch" % args.context, "value": round(gb * args.steps / dt, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
@@ -235,6 +287,16 @@ def main():
         res["roofline"] = roof
         res["roofline_attention"] = extra
         res["kernels"] = table
+    if world > 1:
+        # GPU time between the end of the backward pass and the end of the gradient exchange, averaged over the timed steps: what the
+        # all-reduce costs beyond what the backward hides
+        res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
+        res["overlap"] = not args.no_overlap
+    if world == 1 and not args.no_eager_baseline:
+        res["eager_rocm_baseline"] = eager_rocm_baseline(args.context, layers, args.vocab, shape, args.batch, dev)
+        v = res["eager_rocm_baseline"].get("fp32_clean")
+        if isinstance(v, float):
+            res["speedup_vs_eager_rocm_fp32"] = round(res["value"] / v, 2)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.context, layers, args.vocab)
     print(json.dumps(res), flush=True)

@@ -27,7 +27,7 @@ __device__ __forceinline__ int tile_off(int row, int ch) { return row * ROW_BYTE
 
 // stage rows [0,n_valid) of a [*, ld] bf16 matrix slice (64 columns) into an LDS tile of npad rows
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, int64_t ld, int n_valid, int npad, int tid) {
-  for (int c = tid; c < npad * 8; c += 256) {
+  for (int c = tid; c < npad * 8; c += blockDim.x) {
     const int row = c >> 3, ch = c & 7;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < n_valid) v = *reinterpret_cast<const uint4*>(base + (int64_t)row * ld + ch * 8);
@@ -82,8 +82,11 @@ struct AttnArgs {
 // --------------------------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------------------------
+// Long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU: those launches use
+// 8 waves per block (two per SIMD) instead of 4 -- with one wave per SIMD nothing hides the MFMA -> softmax -> MFMA dependency chain
+// (stress shape, B = 32: forward 88.7 us, backward 252 us at 4 waves).
 template <int NKT>
-__global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NKT <= 12 ? 256 : 512, NKT <= 12 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPAD = NKT * 16;
   unsigned char* Ks = smem;
@@ -99,7 +102,8 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnAr
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   unsigned seed_lo = a.seed_lo, seed_hi = a.seed_hi, off_lo = a.off_lo, off_hi = a.off_hi;
   if (a.thr16) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
-  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += nwaves) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     bf16x8 qf[2];
 #pragma unroll
@@ -191,7 +195,109 @@ __global__ __launch_bounds__(256, NKT <= 12 ? 3 : 1) void attn_fwd_kernel(AttnAr
 // --------------------------------------------------------------------------------------------
 // backward, pass 1: dQ (query per lane; K and V in LDS); also emits delta = rowsum(dO * O)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
+template <int NKT>
+__global__ __launch_bounds__(NKT <= 12 ? 256 : 512, NKT <= 12 ? 3 : 2) void attn_bwd_dq_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int NPAD = NKT * 16;
+  unsigned char* Ks = smem;
+  unsigned char* Vs = smem + NPAD * ROW_BYTES;
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int N = a.N, Dm = a.H * HD;
+  const int64_t ld = 3 * (int64_t)Dm;
+  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
+  stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  __syncthreads();
+
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int nwaves = blockDim.x >> 6;
+  for (int mt = wave; mt * 16 < N; mt += nwaves) {
+    const int q = mt * 16 + i, qc = q < N ? q : N - 1;
+    const int64_t orow = ((int64_t)b * N + qc) * Dm + h * HD;
+    bf16x8 qf[2], dof[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
+      dof[ks] = *reinterpret_cast<const bf16x8*>(a.dout + orow + 32 * ks + 8 * g);
+    }
+    const float lse = a.lse2[(int64_t)bh * N + qc];
+    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
+    const uint32_t* kp = a.keep ? a.keep + ((int64_t)bh * N + qc) * a.NW : nullptr;
+    // One pass over the keys: P and the dropout-scaled dP of the whole row stay in registers (N <= 384 keys = 96 + 96 values per lane at most),
+    // delta = sum_k P_k * dP_k in fp32 from them (== rowsum(dO*O) of the exact forward; taking it from the bf16-stored O instead costs ~3e-3
+    // relative error in dQ/dK).  (The first version recomputed S and dP with the MFMAs -- and the exponentials -- in a second pass.)
+    constexpr bool KEEP_DP = true;
+    f32x4 pr[NKT], dpr[KEEP_DP ? NKT : 1];
+    float delta = 0.f;
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) {
+      const unsigned aw = ap[w], kw = kp ? kp[w] : 0xffffffffu;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int t = 2 * w + half;
+        f32x4 acc_s = {0.f, 0.f, 0.f, 0.f}, acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          acc_s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc_s, 0, 0, 0);
+          acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dof[ks], acc_dp, 0, 0, 0);
+        }
+        const unsigned na = (aw >> (half * 16 + 4 * g)) & 0xFu, nk = (kw >> (half * 16 + 4 * g)) & 0xFu;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = ((na >> r) & 1u) ? __builtin_amdgcn_exp2f(acc_s[r] * a.scale_log2 - lse) : 0.f;
+          const float dpe = ((nk >> r) & 1u) ? acc_dp[r] * a.inv_keep : 0.f;
+          pr[t][r] = p;
+          if (KEEP_DP) dpr[KEEP_DP ? t : 0][r] = dpe;
+          delta += p * dpe;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one 32-key slab at a time: hoisting every K / V fragment read costs the registers of a wave of occupancy
+    }
+    delta = xgroup_sum(delta);
+    f32x4 dq[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) {
+      float dsv[8];
+      if (KEEP_DP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dsv[e] = pr[2 * w + (e >> 2)][e & 3] * (dpr[KEEP_DP ? 2 * w + (e >> 2) : 0][e & 3] - delta) * a.scale;
+      } else {
+        const unsigned kw = kp ? kp[w] : 0xffffffffu;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int t = 2 * w + half;
+          f32x4 acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Vs, 16 * t + i, 4 * ks + g), dof[ks], acc_dp, 0, 0, 0);
+          const unsigned nk = (kw >> (half * 16 + 4 * g)) & 0xFu;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsv[half * 4 + r] = pr[t][r] * ((((nk >> r) & 1u) ? acc_dp[r] * a.inv_keep : 0.f) - delta) * a.scale;
+        }
+      }
+      bf16x8 dsa, dsl;
+      split_pack8(dsv, dsa, dsl);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const bf16x8 kt_ = lds_col_frag(Ks, w, dt, i, g);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsa, dq[dt], 0, 0, 0);
+        dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kt_, dsl, dq[dt], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (q < N) {
+      bf16_t* dst = a.dqkv + ((int64_t)b * N + q) * ld + h * HD + 4 * g;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+        *reinterpret_cast<uint2*>(dst + 16 * dt) = make_uint2(pack_bf16x2(dq[dt][0], dq[dt][1]), pack_bf16x2(dq[dt][2], dq[dt][3]));
+      if (g == 0) a.delta[(int64_t)bh * N + q] = delta;
+    }
+  }
+}
+
+// two-pass form (S and dP recomputed in the second pass): 24 key tiles, where a whole row of P does not fit in registers next to the rest
+__global__ __launch_bounds__(512, 2) void attn_bwd_dq2_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NPAD = a.nkt * 16;
   unsigned char* Ks = smem;
@@ -205,7 +311,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  for (int mt = wave; mt * 16 < N; mt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int mt = wave; mt * 16 < N; mt += nwaves) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     const int64_t orow = ((int64_t)b * N + qc) * Dm + h * HD;
     bf16x8 qf[2], dof[2];
@@ -283,7 +390,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnArgs a) {
 // --------------------------------------------------------------------------------------------
 // backward, pass 2: dK, dV (key per lane; Q, dO, lse, delta and the transposed bit rows in LDS)
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
+template <int NT>      // 256 threads (<= 12 key tiles) or 512 (16 / 24): the bound is the register budget the compiler works with
+__global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int NPAD = a.nkt * 16, NW = a.NW;
   unsigned char* Qs = smem;
@@ -299,12 +407,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
   stage_tile(Qs, qbase, ld, N, NPAD, tid);
   stage_tile(dOs, a.dout + (int64_t)b * N * Dm + h * HD, Dm, N, NPAD, tid);
-  for (int qi = tid; qi < NPAD; qi += 256) {
+  for (int qi = tid; qi < NPAD; qi += blockDim.x) {
     lse_s[qi] = qi < N ? a.lse2[(int64_t)bh * N + qi] : INFINITY;
     del_s[qi] = qi < N ? a.delta[(int64_t)bh * N + qi] : 0.f;
   }
   const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh;
-  for (int c = tid; c < NPAD * NW; c += 256) {
+  for (int c = tid; c < NPAD * NW; c += blockDim.x) {
     const int qi = c / NW, w = c - qi * NW;
     allowT[w * NPAD + qi] = qi < N ? ap[(int64_t)qi * NW + w] : 0u;
     keepT[w * NPAD + qi] = (qi < N && a.keep) ? a.keep[((int64_t)bh * N + qi) * NW + w] : 0xffffffffu;
@@ -312,7 +420,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AttnArgs a) {
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  for (int kt = wave; kt * 16 < N; kt += 4) {
+  const int nwaves = blockDim.x >> 6;
+  for (int kt = wave; kt * 16 < N; kt += nwaves) {
     const int key = kt * 16 + i, kc = key < N ? key : N - 1;
     bf16x8 kf[2], vf[2];
 #pragma unroll
@@ -403,7 +512,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once = true;
   }
-  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(256), lds, st>>>(a);
+  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(NKT <= 12 ? 256 : 512), lds, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -472,13 +581,29 @@ extern "C" int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2
   const size_t lds2 = lds1 + (size_t)NPAD * 8 + (size_t)2 * a.NW * NPAD * 4;
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<256>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dkdv_kernel<512>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     once = true;
   }
-  attn_bwd_dq_kernel<<<dim3(B * H), dim3(256), lds1, st>>>(a);
+  const dim3 blk(a.nkt <= 12 ? 256 : 512);
+  switch (a.nkt) {
+    case 2: attn_bwd_dq_kernel<2><<<dim3(B * H), blk, lds1, st>>>(a); break;
+    case 4: attn_bwd_dq_kernel<4><<<dim3(B * H), blk, lds1, st>>>(a); break;
+    case 8: attn_bwd_dq_kernel<8><<<dim3(B * H), blk, lds1, st>>>(a); break;
+    case 12: attn_bwd_dq_kernel<12><<<dim3(B * H), blk, lds1, st>>>(a); break;
+    case 16: attn_bwd_dq_kernel<16><<<dim3(B * H), blk, lds1, st>>>(a); break;
+    case 24: attn_bwd_dq2_kernel<<<dim3(B * H), blk, lds1, st>>>(a); break;
+    default: return SAM_ERR_UNSUPPORTED;
+  }
   SAM_LAUNCH_CHECK();
-  attn_bwd_dkdv_kernel<<<dim3(B * H), dim3(256), lds2, st>>>(a);
+  if (a.nkt <= 12) attn_bwd_dkdv_kernel<256><<<dim3(B * H), blk, lds2, st>>>(a);
+  else attn_bwd_dkdv_kernel<512><<<dim3(B * H), blk, lds2, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -60,6 +60,7 @@ class Trainer:
         self.epoch_id, self.current_val_score = 0, None
         self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
         self._graph, self._graph_sig, self._graph_warm = None, None, False
+        self.measure_comm, self._comm_events = False, []
         dropout_clock.manual_seed((int(seed) ^ (rank << 32)) & 0xFFFFFFFFFFFFFFFF)       # data-parallel replicas draw different masks
 
     # ---- data-parallel layout ------------------------------------------------------------------------------
@@ -178,7 +179,13 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
         parallel.active_reducer = None
         if self.reducer is not None:
+            if self.measure_comm:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             self.reducer.finish()                               # waits for the overlapped all-reduces
+            if self.measure_comm:
+                e1.record()
+                self._comm_events.append((e0, e1))
         ops.sumsq(flat.grad, self.gnorm_sq)                    # global norm AFTER the all-reduce, as the reference clips reduced grads
         if sched_dev is None:
             ops.adam_step(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self.current_lrs(),
@@ -265,6 +272,15 @@ class Trainer:
             ops.set_rng_state(None)                                           # the captured launches keep the pointer; eager launches go back to by-value
             dropout_clock.offset = saved_offset
         self._graph, self._graph_sig, self._static_in = g, sig, static_in
+
+    def exposed_comm_ms(self):
+        """mean GPU time of reducer.finish() (backward done -> every bucket reduced) over the steps run with measure_comm set"""
+        if not self._comm_events:
+            return 0.0
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._comm_events]
+        self._comm_events = []
+        return sum(ms) / len(ms)
 
     # ---- checkpoint in the reference's layout (train.py:177-187) ------------------------------------------
     def _torch_optimizer(self, with_state):
