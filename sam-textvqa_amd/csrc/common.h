@@ -113,6 +113,13 @@ __device__ __forceinline__ u32x4 dropout_bits128(unsigned c0, unsigned c1, unsig
   const unsigned base = mix32(c0 * 0x9E3779B1u + (c2 ^ k0)) ^ (c1 * 0x85EBCA77u + c3 * 0xC2B2AE3Du + k1);
   return {mix32(base), mix32(base + 0x68E31DA4u), mix32(base + 0xB5297A4Du), mix32(base + 0x1B56C4E9u)};
 }
+// Hidden-state dropout (GEMM epilogues of BertSelfOutput / BertOutput, regenerated by the LayerNorm backward; the embedding dropout of
+// PrevPredEmbeddings): 8 x 16 random bits per (row, 8-column group).  Philox4x32-10 here cost as much VALU as an erf-GELU per element
+// (20 quarter-rate integer multiplies per call: +4..15 us on every dropout epilogue, +6 us on each LayerNorm backward); the counter hash
+// above draws the same 128 bits for a third of the instructions.
+__device__ __forceinline__ u32x4 hidden_dropout_bits(unsigned row, unsigned col8, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {
+  return dropout_bits128(row, col8, off_lo, off_hi, seed_lo, seed_hi);
+}
 // dropout threshold on 16-bit lanes of the random words: element kept iff rnd16 >= thr16
 __host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {
   float t = p * 65536.0f + 0.5f;

@@ -26,7 +26,7 @@ __device__ __forceinline__ void st4bf(bf16_t* p, const float* v) {
 // keep mask of 4 consecutive columns (chunk c = col / 4) of `row`: the (row, col / 8) Philox stream the GEMM / LN epilogues use
 __device__ __forceinline__ void dropout4(float* v, unsigned row, int c, unsigned thr16, float inv_keep, unsigned seed_lo, unsigned seed_hi,
                                          unsigned off_lo, unsigned off_hi) {
-  const u32x4 rn = philox4x32_10(row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
+  const u32x4 rn = hidden_dropout_bits(row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
   const unsigned lo = (c & 1) ? rn.z : rn.x, hi = (c & 1) ? rn.w : rn.y;
   v[0] = (lo & 0xffffu) >= thr16 ? v[0] * inv_keep : 0.f;
   v[1] = (lo >> 16) >= thr16 ? v[1] * inv_keep : 0.f;

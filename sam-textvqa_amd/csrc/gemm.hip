@@ -289,7 +289,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, i
     }
     if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
       if (p.thr16) {   // same (row, col/8) Philox stream as the in-GEMM epilogue
-        const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+        const u32x4 rn = hidden_dropout_bits((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
         const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
         v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
         v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;

@@ -300,7 +300,7 @@ __device__ __forceinline__ void defer_slice(const GemmArgs& p, const f32x4 (&pac
   }
   if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
     if (p.thr16) {      // the (row, col/8) Philox stream of every other epilogue of the family
-      const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+      const u32x4 rn = hidden_dropout_bits((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
       const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
       for (int r = 0; r < W / 2; ++r) {

@@ -141,7 +141,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x
       }
       if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
         if (p.thr16) {
-          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+          const u32x4 rn = hidden_dropout_bits((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
           const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
           v[0] = (lo & 0xffffu) >= p.thr16 ? v[0] * p.inv_keep : 0.f;
           v[1] = (lo >> 16) >= p.thr16 ? v[1] * p.inv_keep : 0.f;
@@ -257,7 +257,7 @@ __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32
       }
       if (EPI == SAM_EPI_BIAS_DROPOUT_RES) {
         if (p.thr16) {
-          const u32x4 rn = philox4x32_10((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+          const u32x4 rn = hidden_dropout_bits((unsigned)m, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
           const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
