@@ -111,6 +111,11 @@ int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
  * weight gradients of an encoder layer (dWqkv, dWo, dW1, dW2: 432 tiles of 128x128) fill the 512 resident block slots in a single
  * round, which makes split-K and its reduction pass unnecessary.  bias_grad is honoured per problem. */
 int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);
+/* Workspace of the grouped call.  With descs[0].ws / ws_bytes >= this many bytes (16-byte aligned, ZERO-FILLED once by the caller, private to one
+ * stream; every launch leaves its flag words zero again) and every K a multiple of 64, the call runs 256x256 tiles on the 8-wave kernel with each
+ * tile's K range split over a PAIR of workgroups that exchange accumulator halves inside the launch (fixed summation order, no atomics).
+ * Without it the 128x128 4-wave kernel runs.  descs[0].force_tile: 0 = choose, 128 = 4-wave kernel, 1256 = 8-wave kernel or error. */
+int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count);
 /* C[m,n] += sum_s ws[s][m,n] ; bias_grad[m] += sum_s ws_bias[s][m]  (ws layout as written by sam_gemm_bf16; fixed order) */
 int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream);
 

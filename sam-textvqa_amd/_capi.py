@@ -39,6 +39,7 @@ SIGNATURES = {
     "sam_gemm_bf16": [C.POINTER(GemmDesc), _vp],
     "sam_gemm_splitk_reduce": [_vp, _i, _i, _i, _vp, _i64, _vp, _vp],
     "sam_gemm_bf16_grouped": [C.POINTER(GemmDesc), _i, _vp],
+    "sam_gemm_grouped_ws_bytes": [C.POINTER(GemmDesc), _i],
     "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],
     "sam_layernorm_bwd": [_vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _f, _u64, _u64, _vp, _vp, _vp, _i, _vp, _vp],
     "sam_layernorm_bwd_ws_bytes": [_i],
@@ -62,8 +63,8 @@ SIGNATURES = {
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "sam_set_rng_state": [_vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
-RET_I64 = {"sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 
 _lib = None
 

@@ -444,6 +444,19 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     total += (a.tiles_m * a.tiles_n + 7) / 8 * 8;     // keep every problem's first block on XCD 0
   }
   g.start[count] = total;
+  // first choice: the 8-wave kernel with in-launch pair exchange (gemm8w.hip); it declines (K % 64, no workspace, tile counts it is not built for)
+  // without touching the error string.  descs[0].force_tile: 128 = this file's 4-wave kernel, 1256 = the 8-wave kernel or an error.
+  {
+    static int use8 = -1;
+    if (use8 < 0) { const char* e = getenv("SAM_GEMM8W"); use8 = e ? atoi(e) : 1; }
+    const int ft = descs[0].force_tile;
+    SAM_REQUIRE(ft == 0 || ft == 128 || ft == 1256, "sam_gemm_bf16_grouped: force_tile must be 0, 128 or 1256");
+    if ((use8 && ft == 0) || ft == 1256) {
+      const int rc = gemm8w_grouped(descs, count, (hipStream_t)stream);
+      if (rc == SAM_OK) return SAM_OK;
+      SAM_REQUIRE(rc == SAM_ERR_UNSUPPORTED && ft != 1256, "sam_gemm_bf16_grouped: the 8-wave grouped kernel cannot run this problem set (K %% 64, workspace, tile count)");
+    }
+  }
   static bool once = false;
   if (!once) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2);
@@ -456,6 +469,13 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float><<<dim3(total), dim3(256), (size_t)2 * (128 + 128) * BK * 2, (hipStream_t)stream>>>(g);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
+}
+
+extern "C" int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count) {
+  if (!descs || count < 1 || count > 8) return 0;
+  int tiles = 0;
+  for (int q = 0; q < count; ++q) tiles += ((descs[q].M + 255) / 256) * ((descs[q].N + 255) / 256);
+  return gemm8w_ws_bytes(tiles);
 }
 
 extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream) {

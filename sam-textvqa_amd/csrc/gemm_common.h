@@ -293,5 +293,10 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.
 int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
+// grouped weight gradients on the 8-wave core (gemm8w.hip): 256x256 tiles, the K range of each tile split over a PAIR of blocks that exchange
+// halves inside the launch.  descs[0].ws / ws_bytes: the exchange workspace (gemm8w_ws_bytes(total tiles); its first words are the pair flags,
+// which must be zero before the first launch and are left zero by every launch).  SAM_ERR_UNSUPPORTED: not a problem set for this kernel.
+int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st);
+int64_t gemm8w_ws_bytes(int tiles);
 
 }  // namespace samgemm

@@ -14,6 +14,8 @@
 #include <torch/library.h>
 
 #include <tuple>
+#include <map>
+#include <mutex>
 #include <vector>
 
 #include "sam_hip.h"
@@ -87,6 +89,17 @@ void wgrad_grouped(const std::vector<WgradJob>& jobs) {
     d[q].A = j.dy->data_ptr(); d[q].lda = j.dy->stride(0); d[q].B = j.x->data_ptr(); d[q].ldb = j.x->stride(0);
     d[q].C = j.dw->data_ptr(); d[q].ldc = j.dw->stride(0);
     d[q].bias_grad = j.db ? (float*)j.db->data_ptr() : nullptr;
+  }
+  // exchange workspace of the 8-wave grouped kernel: one zero-filled buffer per (device, stream), grown on demand; the kernel leaves its flag words
+  // zero and launches on one stream are ordered, so consecutive calls share it
+  {
+    static std::mutex mu;
+    static std::map<std::pair<int, void*>, Tensor> cache;
+    const int64_t bytes = sam_gemm_grouped_ws_bytes(d, (int)jobs.size());
+    std::lock_guard<std::mutex> lock(mu);
+    Tensor& ws = cache[{(int)jobs[0].dy->get_device(), cur_stream()}];
+    if (!ws.defined() || ws.numel() * 4 < bytes) ws = at::zeros({(bytes + 3) / 4}, jobs[0].dy->options().dtype(at::kFloat));
+    d[0].ws = (float*)ws.data_ptr(); d[0].ws_bytes = ws.numel() * 4;
   }
   ok(sam_gemm_bf16_grouped(d, (int)jobs.size(), cur_stream()), "sam_gemm_bf16_grouped");
 }

@@ -368,7 +368,21 @@ def spatial_relation_tensor(boxes, context=3, distance_threshold=0.5):
     return out
 
 
-def wgrad_grouped(jobs):
+_GROUPED_WS = {}
+
+
+def _grouped_ws(device, nbytes):
+    """exchange workspace of sam_gemm_bf16_grouped: one zero-filled buffer per (device, stream), grown on demand.  The kernel leaves its flag
+    words zero, so the buffer is filled once; launches on one stream are ordered, so they can share it."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _GROUPED_WS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros(((nbytes + 3) // 4,), dtype=torch.float32, device=device)
+        _GROUPED_WS[key] = buf
+    return buf
+
+
+def wgrad_grouped(jobs, force_tile=0):
     """jobs: list of (dy [R,M] bf16, x [R,N] bf16, dW fp32 [M,N] view, dbias fp32 [M] or None).  dW += dy^T x (and dbias += colsum(dy))
     for all jobs in ONE launch (sam_gemm_bf16_grouped)."""
     n = len(jobs)
@@ -381,4 +395,8 @@ def wgrad_grouped(jobs):
         d.A, d.lda, d.B, d.ldb, d.C, d.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
         d.bias_grad = _dp(db)
         flops += 2.0 * d.M * d.N * d.K
+    if force_tile != 128:
+        ws = _grouped_ws(jobs[0][0].device, int(capi.lib().sam_gemm_grouped_ws_bytes(arr, n)))
+        arr[0].ws, arr[0].ws_bytes = ws.data_ptr(), ws.numel() * 4
+    arr[0].force_tile = force_tile
     capi.call("sam_gemm_bf16_grouped", arr, n, capi.stream_handle(), meta=dict(kernel="gemm_grouped_wgrad", flops=flops, shape=(n,)))
