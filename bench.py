@@ -78,10 +78,11 @@ def pmc_traffic(kernel_key):
     if m:
         tf = {"0": "false", "1": "true"}
         pat = re.compile(r"gemm_kernel<\d+, \d+, \d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
-        sel = [v for k, v in kern.items() if pat.match(k)]
+        pat8 = re.compile(r"gemm8_kernel<\d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
+        sel = [v for k, v in kern.items() if pat.match(k) or pat8.match(k)]
     else:
         names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"],
-                 "gemm_grouped_wgrad": ["gemm_group_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
+                 "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
         sel = [v for k, v in kern.items() if any(k.startswith(n) for n in names)]
     n = sum(v["launches_profiled"] for v in sel)
     if not n:
@@ -99,7 +100,7 @@ def pmc_mfma_util(kernel_key):
         return None
     kern = json.load(open(files[-1]))["kernels"]
     if kernel_key == "gemm_grouped_wgrad":
-        sel = [v for k, v in kern.items() if k.startswith("gemm_group_kernel")]
+        sel = [v for k, v in kern.items() if k.startswith("gemm8w_kernel")] or [v for k, v in kern.items() if k.startswith("gemm_group_kernel")]
         return sel[0]["mfma_util"] if sel else None
     return None
 
