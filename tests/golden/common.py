@@ -76,6 +76,7 @@ MMT_CASES = {  # whole MMT (PrevPredEmbeddings + n/s encoder), fwd + bwd
     "mmt_small_c3": dict(dims=SMALL, ctx=3, layers=["n", "s", "s"], quadrants=[1, 2]),
     "mmt_small_c5": dict(dims=SMALL, ctx=5, layers=["n", "n", "s"], quadrants=[1, 2]),
     "mmt_full_c3": dict(dims=FULL, ctx=3, layers=["n", "n", "s", "s", "s", "s"], quadrants=[1, 2]),
+    "mmt_full_c5": dict(dims=FULL, ctx=5, layers=["n", "n", "s", "s", "s", "s"], quadrants=[1, 2]),   # configs/train-tvqa-eval-tvqa-c5.yml:52-54
 }
 SAM4C_CASES = {  # whole model incl. TextBert, input encoders, pointer net, loss
     "sam4c_small_c3": dict(dims=dict(SMALL, n_ocr=50, n_ocr_valid=[11, 0]), ctx=3, layers=["n", "s"],

@@ -17,12 +17,35 @@ from tests.golden import common as C
 
 pytestmark = pytest.mark.gpu
 
+# Limits of the model-level comparisons (relative to max |ref| unless noted): about 2x the error the HIP path achieves (run with -s for the
+# PARITY lines).  The per-kernel 1e-3 bound lives in the kernel tests; these bound the accumulation of bf16 storage roundings through depth.
+L = dict(layer_out_o=0.013, layer_dh_o=0.016, layer_out_g=0.014, layer_dh_g=0.016, layer_ctx_g=0.009, layer_pgrad_g=0.012,   # achieved 0.4-0.8 %
+         mmt_seq_g=0.03, mmt_dleaf_g=0.035, mmt_pgrad_g=0.04,                      # six layers, c=3 and c=5: achieved 1.0-2.0 %
+         alone_vs_batch=0.007,                                                    # other tile shapes / split-K: achieved 0.35 %
+         sam4c_scores=0.004, sam4c_loss=5e-5, sam4c_pgrad=0.017,                   # achieved 0.19 %, 6e-6, 0.85 %
+         stress_seq=0.03, stress_grad=0.026, greedy_agree=0.95)                    # achieved 1.4 %, 1.3 %, 1.00
+
 
 def rel_err(got, ref):
     got, ref = got.detach().float().cpu().double(), torch.as_tensor(ref).double()
     assert got.shape == ref.shape, (got.shape, ref.shape)
     assert torch.isfinite(got).all()
     return ((got - ref).abs().max() / ref.abs().max()).item()
+
+
+def within(name, err, limit):
+    """parity bound with the achieved error on record: limits are set at about twice what the kernels reach (printed with -s), so a
+    mid-size defect in one layer of six cannot hide under a depth-scaled allowance"""
+    print("PARITY %-58s achieved %.3e  limit %.3e" % (name, err, limit))
+    assert err < limit, "%s: error %.3e exceeds %.3e" % (name, err, limit)
+
+
+def score_err(out, ref):
+    """relative-to-max error of the answer scores over the entries that are not the literal -10000 of padded OCR columns (sa_m4c.py:893)"""
+    out, ref = out.detach().float().cpu().double(), ref.detach().double()
+    live = ref > -9000
+    assert ((out < -9000) == ~live).all()
+    return ((out - ref).abs()[live].max() / ref[live].abs().max()).item()
 
 
 def bf16_round_module(m):
@@ -52,22 +75,23 @@ def test_spatial_layer_full_size_vs_reference_golden():
     hb = hidden.detach().to(torch.bfloat16).float().requires_grad_(True)
     oo = o_layer(hb, ext, adj)[0]
     (oo * gout).sum().backward()
-    assert rel_err(out, oo) < 8 * 2.0 ** -8, rel_err(out, oo)
-    assert rel_err(h.grad, hb.grad) < 16 * 2.0 ** -8, rel_err(h.grad, hb.grad)
-    assert rel_err(out, g["out"]) < 10 * 2.0 ** -8 and rel_err(h.grad, g["d_hidden"]) < 20 * 2.0 ** -8
+    within("layer out vs oracle(bf16 weights)", rel_err(out, oo), L["layer_out_o"])
+    within("layer d_hidden vs oracle(bf16 weights)", rel_err(h.grad, hb.grad), L["layer_dh_o"])
+    within("layer out vs reference golden", rel_err(out, g["out"]), L["layer_out_g"])
+    within("layer d_hidden vs reference golden", rel_err(h.grad, g["d_hidden"]), L["layer_dh_g"])
     # text rows of a spatial layer: context is exactly 0 (sa_m4c.py:574-584)
     ctx = layer.attention.self(h.detach(), ext.cuda(), adj.cuda())[0]
     assert (ctx[:, : d["T"]] == 0).all()
-    assert rel_err(ctx, g["ctx"]) < 4 * 2.0 ** -8
+    within("layer attention context vs reference golden", rel_err(ctx, g["ctx"]), L["layer_ctx_g"])
     for pn, p in layer.named_parameters():
         if "grad." + pn in g:
-            e = rel_err(p.grad, g["grad." + pn])
-            assert e < 24 * 2.0 ** -8, (pn, e)
+            within("layer grad " + pn, rel_err(p.grad, g["grad." + pn]), L["layer_pgrad_g"])
 
 
-def test_mmt_full_size_vs_reference_golden():
+@pytest.mark.parametrize("name", ["mmt_full_c3", "mmt_full_c5"])
+def test_mmt_full_size_vs_reference_golden(name):
+    """the shipped c=3 and c=5 encoders (configs/train-tvqa-eval-tvqa-c{3,5}.yml: n,n,s,s,s,s) at full size against the REFERENCE's outputs"""
     import sam_textvqa_amd.modules as M
-    name = "mmt_full_c3"
     o_mmt, bd, leaves, gout, g = OC.mmt_case(name)
     case = C.MMT_CASES[name]
     d = case["dims"]
@@ -82,16 +106,13 @@ def test_mmt_full_size_vs_reference_golden():
         gbd[k] = gl[k]
     seq = mmt(gbd, fixed_ans_emb=gl["fixed_ans_emb"])["mmt_seq_output"]
     (seq.float() * gout.cuda()).sum().backward()
-    e = rel_err(seq, g["seq"])
-    assert e < 40 * 2.0 ** -8, e                 # 6 layers x ~7 bf16 re-roundings each
+    within(name + " seq vs reference golden", rel_err(seq, g["seq"]), L["mmt_seq_g"])
     for k in leaves:
-        e = rel_err(gl[k].grad, g["d_" + k])
-        assert e < 80 * 2.0 ** -8, (k, e)
+        within(name + " d_" + k, rel_err(gl[k].grad, g["d_" + k]), L["mmt_dleaf_g"])
     for pn, p in mmt.named_parameters():
         if "grad." + pn in g:
             ref = g["grad." + pn]
-            e = rel_err(p.grad[: ref.shape[0]] if ref.shape != tuple(p.shape) else p.grad, ref)
-            assert e < 80 * 2.0 ** -8, (pn, e)
+            within(name + " grad " + pn, rel_err(p.grad[: ref.shape[0]] if ref.shape != tuple(p.shape) else p.grad, ref), L["mmt_pgrad_g"])
 
 
 def test_state_dict_keys_match_oracle_and_roundtrip():
@@ -154,13 +175,12 @@ def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
     loss.backward()
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(out_ref.shape)
-    e = rel_err(out, out_ref.detach())
-    assert e < 0.03, e
-    assert abs(loss.item() - loss_ref.item()) < 0.01 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    within("sam4c scores c=%d" % ctx, score_err(out, out_ref), L["sam4c_scores"])
+    within("sam4c loss c=%d" % ctx, abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), L["sam4c_loss"])
     # padded OCR columns carry the literal -10000 (sa_m4c.py:893)
     pad = (bd_cpu["pad_ocr_mask"] == 0)
     assert (out.cpu()[:, :, 300:][pad.unsqueeze(1).expand(-1, out.shape[1], -1)] < -9000).all()
-    bad = []
+    bad, worst = [], 0.0
     refp = dict(ref.named_parameters())
     biggest = max(p.grad.norm().item() for p in ref.parameters() if p.grad is not None)
     for pn, p in model.named_parameters():
@@ -170,34 +190,145 @@ def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
             assert p.grad.norm().item() < 1e-2 * biggest, pn
             continue
         e = ((p.grad.cpu().double() - g_ref.double()).norm() / g_ref.double().norm()).item()
-        if e > 0.05:
+        worst = max(worst, e)
+        if e > L["sam4c_pgrad"]:
             bad.append((pn, round(e, 4)))
+    within("sam4c worst parameter-gradient norm error c=%d" % ctx, worst, L["sam4c_pgrad"])
     assert not bad, bad
 
 
-def test_mmt_stress_shape_runs_and_matches_oracle():
-    """BASELINE config 5 shapes: 200 obj + 100 OCR + 30 dec (+20 text) = 350 tokens; 1 sample, 2 layers"""
+def test_mmt_stress_shape_forward_backward_vs_oracle():
+    """BASELINE config 5 shapes: 200 obj + 100 OCR + 30 dec (+20 text) = 350 tokens (the NKT = 24 attention template, the 128 KB-LDS backward);
+    2 samples with different padding, layers n,s,s; output AND the gradients of every input and parameter against the fp32 oracle"""
     import sam_textvqa_amd.modules as M
     from sam_textvqa_amd.synthetic import make_batch, mmt_config_dict
     shapes = (20, 200, 100, 30)
-    md = mmt_config_dict(3, ("n", "s"), n_dec=30, T=20, n_obj=200, n_ocr=100)
+    md = mmt_config_dict(3, ("n", "s", "s"), n_dec=30, T=20, n_obj=200, n_ocr=100)
     md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
     torch.manual_seed(1)
     ref = O.MMT(O.BertConfig.from_dict(md)).eval()
+    with torch.no_grad():
+        for p in ref.parameters():
+            if p.dim() == 1:
+                p.add_(0.05 * torch.randn_like(p))
     mmt = M.MMT(M.BertConfig.from_dict(md)).eval()
     mmt.load_state_dict(ref.state_dict()); mmt.cuda()
-    bd = make_batch(1, *shapes, vocab=100, device="cpu", seed=5)
+    bd = make_batch(2, *shapes, vocab=100, device="cpu", seed=5)
     g = torch.Generator().manual_seed(2)
-    extra = dict(text_bert_emb=torch.randn(1, 20, 768, generator=g), obj_mmt_in=torch.randn(1, 200, 768, generator=g),
-                 ocr_mmt_in=torch.randn(1, 100, 768, generator=g))
-    ans = torch.randn(100, 768, generator=g)
-    bd.update(extra)
-    with torch.no_grad():
-        seq_ref = ref(dict(bd), fixed_ans_emb=ans)["mmt_seq_output"]
-        gbd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd.items()}
-        seq = mmt(gbd, fixed_ans_emb=ans.cuda())["mmt_seq_output"]
-    assert seq.shape == (1, 350, 768)
-    assert rel_err(seq, seq_ref) < 0.03
+    leaves = dict(text_bert_emb=torch.randn(2, 20, 768, generator=g), obj_mmt_in=torch.randn(2, 200, 768, generator=g),
+                  ocr_mmt_in=torch.randn(2, 100, 768, generator=g), fixed_ans_emb=torch.randn(100, 768, generator=g))
+    gout = torch.randn(2, 350, 768, generator=g)
+    rl = {k: v.clone().requires_grad_(True) for k, v in leaves.items()}
+    rbd = dict(bd); rbd.update({k: rl[k] for k in ("text_bert_emb", "obj_mmt_in", "ocr_mmt_in")})
+    seq_ref = ref(rbd, fixed_ans_emb=rl["fixed_ans_emb"])["mmt_seq_output"]
+    (seq_ref * gout).sum().backward()
+    gl = {k: v.clone().cuda().requires_grad_(True) for k, v in leaves.items()}
+    gbd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd.items()}
+    gbd.update({k: gl[k] for k in ("text_bert_emb", "obj_mmt_in", "ocr_mmt_in")})
+    seq = mmt(gbd, fixed_ans_emb=gl["fixed_ans_emb"])["mmt_seq_output"]
+    (seq.float() * gout.cuda()).sum().backward()
+    assert seq.shape == (2, 350, 768)
+    within("stress seq", rel_err(seq, seq_ref.detach()), L["stress_seq"])
+    for k in leaves:
+        within("stress d_" + k, rel_err(gl[k].grad, rl[k].grad), L["stress_grad"])
+    refp = dict(ref.named_parameters())
+    biggest = max(p.grad.norm().item() for p in ref.parameters() if p.grad is not None)
+    worst = 0.0
+    for pn, p in mmt.named_parameters():
+        g_ref = refp[pn].grad
+        if g_ref is None or g_ref.norm().item() < 1e-5 * biggest:
+            continue
+        worst = max(worst, ((p.grad.cpu().double() - g_ref.double()).norm() / g_ref.double().norm()).item())
+    within("stress worst parameter-gradient norm error", worst, L["stress_grad"])
+
+
+def test_spatial_layer_is_sample_separable_inside_the_full_batch():
+    """B = 64 at full size (11648 token rows): any sample computed inside the batch -- output, input gradient -- is bit-identical to the same
+    sample computed alone (no cross-sample leakage through tiles, masks or reductions), and the lone sample matches the oracle"""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import make_batch, mmt_config_dict
+    md = mmt_config_dict(3, ("s",))
+    md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    torch.manual_seed(3)
+    o_layer = O.SpatialBertLayer(O.BertConfig.from_dict(md)).eval()
+    layer = M.SpatialBertLayer(M.BertConfig.from_dict(md)).eval()
+    layer.load_state_dict(o_layer.state_dict()); layer.cuda()
+    B, N = 64, 182
+    bd = make_batch(B, vocab=100, context=3, device="cuda", seed=9)
+    mask = torch.cat([bd["question_mask"], bd["pad_obj_mask"], bd["pad_ocr_mask"], torch.ones(B, 12, dtype=torch.long, device="cuda")], 1).float()
+    ext = ((1.0 - mask) * -10000.0)[:, None, None, :].expand(B, 1, N, N).contiguous()
+    adj = bd["spatial_adj_matrices"]["3"]
+    g = torch.Generator(device="cuda").manual_seed(4)
+    hid = torch.randn(B, N, 768, device="cuda", generator=g).to(torch.bfloat16)
+    gout = torch.randn(B, N, 768, device="cuda", generator=g).to(torch.bfloat16)
+    h = hid.clone().requires_grad_(True)
+    out = layer(h, ext, adj)[0]
+    out.backward(gout)
+    # (i) same launch shapes, every OTHER sample replaced: the kept samples must not change by a bit
+    keep = (0, 37, 63)
+    sel = torch.zeros(B, dtype=torch.bool, device="cuda"); sel[list(keep)] = True
+    hid2 = torch.where(sel[:, None, None], hid, torch.randn(B, N, 768, device="cuda", generator=g).to(torch.bfloat16))
+    gout2 = torch.where(sel[:, None, None], gout, torch.randn(B, N, 768, device="cuda", generator=g).to(torch.bfloat16))
+    perm = torch.arange(B, device="cuda"); others = perm[~sel]; perm[~sel] = others.flip(0)
+    perm[list(keep)] = torch.tensor(keep, device="cuda")
+    h2 = hid2.clone().requires_grad_(True)
+    out2 = layer(h2, ext[perm].contiguous().clone().index_copy_(0, torch.tensor(keep, device="cuda"), ext[list(keep)]), adj[perm].contiguous())[0]
+    out2.backward(gout2)
+    for b in keep:
+        assert torch.equal(out2[b], out[b]) and torch.equal(h2.grad[b], h.grad[b]), b
+    assert not torch.equal(out2[1], out[1])
+    # (ii) the sample alone: other tile shapes (and split-K for the 182-row FFN2), so equal up to summation order
+    for b in keep:
+        h1 = hid[b:b + 1].clone().requires_grad_(True)
+        o1 = layer(h1, ext[b:b + 1].contiguous(), adj[b:b + 1].contiguous())[0]
+        o1.backward(gout[b:b + 1])
+        within("sample %d alone vs inside the batch of 64: out" % b, rel_err(o1[0], out[b].float().cpu()), L["alone_vs_batch"])
+        within("sample %d alone vs inside the batch of 64: d_hidden" % b, rel_err(h1.grad[0], h.grad[b].float().cpu()), L["alone_vs_batch"])
+    bf16_round_module(o_layer)
+    hb = hid[37:38].float().cpu().requires_grad_(True)
+    oo = o_layer(hb, ext[37:38].cpu(), adj[37:38].cpu())[0]
+    oo.backward(gout[37:38].float().cpu())
+    within("separable layer sample 37 out vs oracle", rel_err(out[37:38], oo), L["layer_out_o"])
+    within("separable layer sample 37 d_hidden vs oracle", rel_err(h.grad[37:38], hb.grad), L["layer_dh_o"])
+
+
+_STRESS_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["SAM_REPO"])
+os.environ["SAM_FORCE_DIST"] = "1"; os.environ["SAM_REDUCER_CHECK"] = "1"
+from sam_textvqa_amd import parallel
+import sam_textvqa_amd.modules as M
+from sam_textvqa_amd.synthetic import clone_batch, make_batch, mmt_config_dict, text_bert_config_dict
+from sam_textvqa_amd.trainer import Trainer
+parallel.init_distributed()
+shapes = (20, 200, 100, 30)
+md = mmt_config_dict(3, ("n", "n") + ("s",) * 10, n_dec=30, T=20, n_obj=200, n_ocr=100)
+torch.manual_seed(0)
+model = M.SAM4C(M.BertConfig.from_dict(md), M.BertConfig.from_dict(text_bert_config_dict()), num_answers=5000, bos_idx=1)
+tr = Trainer(model, base_lr=1e-4, seed=1)
+assert tr.reducer is not None and tr.reducer.check
+batch = make_batch(32, *shapes, vocab=5000, device="cuda", seed=2)
+losses = [tr.step(clone_batch(batch)).item() for _ in range(3)]
+torch.cuda.synchronize()
+print("LOSSES", losses)
+assert all(l == l and l < 1e4 for l in losses) and losses[-1] < losses[0], losses
+assert all(tr.reducer.done)
+assert torch.isfinite(tr.flat.flat).all()
+print("STRESS_OK")
+"""
+
+
+def test_stress_shape_train_step_b32_twelve_layers_with_reducer_check():
+    """BASELINE config 5 as the bench runs it: B = 32, 350 tokens (M = 11200 rows), 12 layers, dropout on, the data-parallel reducer active in a
+    1-rank RCCL group with SAM_REDUCER_CHECK=1 (every bucket re-verified at finish()); three steps, finite and decreasing loss"""
+    import subprocess
+    import sys
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _STRESS_SCRIPT], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "STRESS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
 def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
@@ -296,7 +427,8 @@ def test_greedy_decode_eval_matches_oracle():
         scores = model(bd)["textvqa_scores"]
     assert (bd["train_prev_inds"][:, 0] == 1).all()                     # BOS
     agree = (bd["train_prev_inds"].cpu() == ref_bd["train_prev_inds"]).float().mean().item()
-    assert agree >= 0.8, agree
+    print("PARITY greedy step agreement %.4f (limit %.2f)" % (agree, L["greedy_agree"]))
+    assert agree >= L["greedy_agree"], agree
     same = (bd["train_prev_inds"].cpu() == ref_bd["train_prev_inds"]).all(dim=1)       # samples whose whole decode path agrees
     if same.any():
         assert rel_err(scores[same.cuda()], ref_scores[same]) < 0.05
@@ -473,17 +605,19 @@ def test_sam4c_degenerate_samples_vs_oracle():
     loss.backward()
     torch.cuda.synchronize()
     assert torch.isfinite(out).all() and torch.isfinite(fp.grad).all()
-    assert rel_err(out, out_ref.detach()) < 0.03
-    assert abs(loss.item() - loss_ref.item()) < 0.01 * abs(loss_ref.item()), (loss.item(), loss_ref.item())
+    within("degenerate samples: scores", score_err(out, out_ref), L["sam4c_scores"])
+    within("degenerate samples: loss", abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), L["sam4c_loss"])
     assert (out[0, :, 300:] < -9000).all()                               # no OCR token: every pointer score is the literal -10000
     refp = dict(ref.named_parameters())
     biggest = max(p.grad.norm().item() for p in ref.parameters() if p.grad is not None)
-    bad = []
+    bad, worst = [], 0.0
     for pn, p in model.named_parameters():
         g_ref = refp[pn].grad
         if g_ref is None or g_ref.norm().item() < 1e-5 * biggest:
             continue
         e = ((p.grad.cpu().double() - g_ref.double()).norm() / g_ref.double().norm()).item()
-        if e > 0.05:
+        worst = max(worst, e)
+        if e > L["sam4c_pgrad"]:
             bad.append((pn, round(e, 4)))
+    within("degenerate samples: worst parameter-gradient norm error", worst, L["sam4c_pgrad"])
     assert not bad, bad
