@@ -243,7 +243,7 @@ def main():
         flat = prepare(model, groups=[g["params"] for g in groups])
         reducer = parallel.GradReducer(flat.grad, overlap=False)
     trainer = Trainer(model, seed=1234 + rank, use_graph=(world == 1 and not args.no_graph), reducer=reducer)
-    trainer.measure_comm = world > 1
+    trainer.measure_comm = trainer.reducer is not None        # (N > 1, or a 1-rank group under SAM_FORCE_DIST=1)
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
 
     for _ in range(args.warmup):
@@ -288,11 +288,12 @@ def main():
         res["roofline"] = roof
         res["roofline_attention"] = extra
         res["kernels"] = table
-    if world > 1:
+    if trainer.reducer is not None:
         # GPU time between the end of the backward pass and the end of the gradient exchange, averaged over the timed steps: what the
         # all-reduce costs beyond what the backward hides
         res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
-        res["overlap"] = not args.no_overlap
+        res["overlap"] = bool(trainer.reducer.overlap)
+        res["grad_payload"] = trainer.reducer.payload
     if world == 1 and not args.no_eager_baseline:
         res["eager_rocm_baseline"] = eager_rocm_baseline(args.context, layers, args.vocab, shape, args.batch, dev)
         v = res["eager_rocm_baseline"].get("fp32_clean")

@@ -134,6 +134,12 @@ int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int x_is_f32, 
 /* bias gradients: out[n] (+)= sum_m x[m,n], x bf16 [M,N]; ws: sam_colsum_ws_bytes(N) */
 int64_t sam_colsum_ws_bytes(int N);
 int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* out, int accumulate, float* ws, void* stream);
+/* ---- element-wise dropout of the object / OCR input encoders, sam/sa_m4c.py:224,263 (F.dropout on LN(feat W) + LN(bbox W)) ----
+ * out = dropout(a + b), bf16 [M,D]; b may be NULL (plain dropout: the backward applies the same mask to dy).  Mask = the hidden-state dropout
+ * stream on (row, col/8) under (seed, offset) [+ the device-side RNG state, sam_set_rng_state]; keep probability quantised to 16 bits as in
+ * SAM_EPI_BIAS_DROPOUT_RES.  D and the row strides must be multiples of 8. */
+int sam_add_dropout_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int M, int D, float p_drop, uint64_t seed,
+                         uint64_t offset, void* stream);
 
 /* ---- M4CDecodingBCEWithMaskLoss, sam/task_utils.py:19-30: forward value AND analytic gradient in one pass ----
  * scores arrive as the two blocks the model produces (classifier logits [R,V] and pointer scores [R,No], both fp32,

@@ -260,6 +260,70 @@ class PrevPredFn(Function):
         return None, g_ans, g_ocr, None, None, None
 
 
+class DropoutFn(Function):
+    """element-wise dropout on bf16 rows with the library's counter-based stream (ops.add_dropout): forward and backward regenerate the same
+    mask from (seed, offset), nothing is stored.  Replaces F.dropout (torch's own Philox stream + a saved mask) on the path."""
+
+    @staticmethod
+    def forward(ctx, x, p_drop):
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.dtype != BF16 or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+            x2 = x2.to(BF16).contiguous()
+        ctx.seed, ctx.p_drop = dropout_clock.next(), p_drop
+        return ops.add_dropout(x2, None, p_drop, *ctx.seed).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+            dy2 = dy2.to(BF16).contiguous()
+        return ops.add_dropout(dy2, None, ctx.p_drop, *ctx.seed).view(dy.shape), None
+
+
+def dropout(x, p_drop, training):
+    return DropoutFn.apply(x, float(p_drop)) if training and p_drop > 0 else x
+
+
+class InputEncoderFn(Function):
+    """dropout(LN_a(feat W_a^T + b_a) + LN_b(bbox W_b^T + b_b)): the object / OCR input encoder (sam/sa_m4c.py:213-224, 252-263) as ONE autograd
+    node -- five launches forward, five backward (dropout mask regenerated, two LayerNorm backwards, two weight gradients; the inputs are
+    features, nothing flows further upstream).  A single node so that, for data parallelism, the end of its backward IS the point at which
+    the eight parameters' gradients are final (`owner._sam_region_id`, parallel.GradReducer.mark_done)."""
+
+    @staticmethod
+    def forward(ctx, anchor, feat, bbox, lin_a, ln_a, lin_b, ln_b, p_drop, owner):
+        wa, _, ba, _, na, _ = _padded_views(lin_a.weight, lin_a.bias)
+        wb, _, bb, _, nb, _ = _padded_views(lin_b.weight, lin_b.bias)
+        if feat.shape[1] != wa.shape[1] or bbox.shape[1] != wb.shape[1] or na != lin_a.weight.shape[0] or nb != lin_b.weight.shape[0]:
+            raise capi.SamHipError("InputEncoderFn: operands must arrive K-padded (ops.l2norm_pack) and out_features must be a multiple of 8")
+        za = ops.gemm(feat, wa, epilogue=capi.EPI_BIAS, bias=ba)
+        zb = ops.gemm(bbox, wb, epilogue=capi.EPI_BIAS, bias=bb)
+        ya, mean_a, rstd_a = ops.layernorm_fwd(za, ln_a.weight, ln_a.bias, ln_a.variance_epsilon)
+        yb, mean_b, rstd_b = ops.layernorm_fwd(zb, ln_b.weight, ln_b.bias, ln_b.variance_epsilon)
+        ctx.seed = dropout_clock.next() if p_drop > 0 else (0, 0)
+        out = ops.add_dropout(ya, yb, p_drop, *ctx.seed)
+        ctx.save_for_backward(feat, bbox, za, mean_a, rstd_a, zb, mean_b, rstd_b)
+        ctx.mods, ctx.p_drop, ctx.owner = (lin_a, ln_a, lin_b, ln_b), p_drop, owner
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        feat, bbox, za, mean_a, rstd_a, zb, mean_b, rstd_b = ctx.saved_tensors
+        lin_a, ln_a, lin_b, ln_b = ctx.mods
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+            dy2 = dy2.to(BF16).contiguous()
+        g = ops.add_dropout(dy2, None, ctx.p_drop, *ctx.seed) if ctx.p_drop > 0 else dy2
+        for lin, ln, x, z, mean, rstd in ((lin_a, ln_a, feat, za, mean_a, rstd_a), (lin_b, ln_b, bbox, zb, mean_b, rstd_b)):
+            dz, _ = ops.layernorm_bwd(g, z, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
+            _, gv, _, dbv, _, _ = _padded_views(lin.weight, lin.bias)
+            ops.gemm(dz, x, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)        # dW += dz^T x ; db += colsum(dz)
+        rid = getattr(ctx.owner, "_sam_region_id", None)
+        if rid is not None and parallel.active_reducer is not None:
+            parallel.active_reducer.mark_done(rid)
+        return (None,) * 9
+
+
 class GradBarrierFn(Function):
     """identity; its backward runs when the COMPLETE gradient of `x` has arrived, i.e. after every consumer of x has run its backward
     (autograd's dependency counting), and then reports `name` to the active gradient reducer.  SAM4C puts one on each of the three

@@ -611,6 +611,53 @@ extern "C" int sam_adam_step_dev(float* p, const float* g, float* m, float* v, v
   return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, stream);
 }
 
+// out = dropout(a [+ b]) on bf16 [M, D] rows: the element-wise dropout of the object / OCR input encoders (sam/sa_m4c.py:224,263: F.dropout on the
+// sum of the two LayerNorm outputs) and, with b = NULL and dy in place of a, its backward (the mask is regenerated from the same counters).
+// One 16-byte chunk per thread = one (row, col / 8) draw of the hidden-state dropout stream.
+__global__ __launch_bounds__(256) void add_dropout_kernel(const bf16_t* __restrict__ a, int64_t lda, const bf16_t* __restrict__ b, int64_t ldb, bf16_t* __restrict__ out,
+                                                          int64_t ldo, int M, int chunks, unsigned thr16, float inv_keep, unsigned seed_lo, unsigned seed_hi,
+                                                          unsigned off_lo, unsigned off_hi, const unsigned long long* rng_state) {
+  rng_resolve(rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  const int64_t total = (int64_t)M * chunks;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int row = (int)(t / chunks), c = (int)(t - (int64_t)row * chunks);
+    const uint4 va = *reinterpret_cast<const uint4*>(a + (int64_t)row * lda + 8 * c);
+    float v[8] = {bf_lo(va.x), bf_hi(va.x), bf_lo(va.y), bf_hi(va.y), bf_lo(va.z), bf_hi(va.z), bf_lo(va.w), bf_hi(va.w)};
+    if (b) {
+      const uint4 vb = *reinterpret_cast<const uint4*>(b + (int64_t)row * ldb + 8 * c);
+      v[0] += bf_lo(vb.x); v[1] += bf_hi(vb.x); v[2] += bf_lo(vb.y); v[3] += bf_hi(vb.y);
+      v[4] += bf_lo(vb.z); v[5] += bf_hi(vb.z); v[6] += bf_lo(vb.w); v[7] += bf_hi(vb.w);
+    }
+    if (thr16) {
+      const u32x4 rn = hidden_dropout_bits((unsigned)row, (unsigned)c, off_lo, off_hi, seed_lo, seed_hi);
+      const unsigned w4[4] = {rn.x, rn.y, rn.z, rn.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[2 * r] = (w4[r] & 0xffffu) >= thr16 ? v[2 * r] * inv_keep : 0.f;
+        v[2 * r + 1] = (w4[r] >> 16) >= thr16 ? v[2 * r + 1] * inv_keep : 0.f;
+      }
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)row * ldo + 8 * c) =
+        make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+  }
+}
+
+extern "C" int sam_add_dropout_bf16(const void* a, int64_t lda, const void* b, int64_t ldb, void* out, int64_t ldo, int M, int D, float p_drop, uint64_t seed,
+                                    uint64_t offset, void* stream) {
+  SAM_REQUIRE(a && out && M > 0 && D > 0 && D % 8 == 0 && lda % 8 == 0 && ldo % 8 == 0 && (!b || ldb % 8 == 0), "sam_add_dropout_bf16: D and the row strides must be multiples of 8");
+  SAM_REQUIRE(((uintptr_t)a % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)b % 16 == 0), "sam_add_dropout_bf16: operands must be 16-byte aligned");
+  SAM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sam_add_dropout_bf16: p_drop out of range");
+  const unsigned thr16 = dropout_thr16(p_drop);
+  const float inv_keep = thr16 ? 1.0f / (1.0f - (float)thr16 / 65536.0f) : 1.0f;
+  const int64_t total = (int64_t)M * (D / 8);
+  const int blocks = (int)min((int64_t)2048, (total + 255) / 256);
+  add_dropout_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)out, ldo, M, D / 8, thr16, inv_keep,
+                                                                         (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32),
+                                                                         sam_get_rng_state());
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 extern "C" int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
   SAM_REQUIRE(x && y && n > 0 && n % 4 == 0, "sam_cast_f32_to_bf16: need n %% 4 == 0");
   const int blocks = (int)min((int64_t)4096, ((n >> 2) + 255) / 256);

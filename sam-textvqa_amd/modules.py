@@ -17,7 +17,7 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, PrevPredFn, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -127,7 +127,7 @@ class BertSelfOutput(_HipModule):
 
     def forward(self, hidden_states, input_tensor):
         self._ready()
-        h = F.dropout(linear(hidden_states.to(BF16), self.dense), self.dropout_p, self.training)
+        h = dropout(linear(hidden_states.to(BF16), self.dense), self.dropout_p, self.training)
         return layer_norm(h + input_tensor.to(BF16), self.LayerNorm)
 
 
@@ -351,7 +351,7 @@ class BertEmbeddings(_HipModule):
         pad = self.word_embeddings.padding_idx
         y = EmbedLayerNormFn.apply(self.LayerNorm.weight, input_ids, self.word_embeddings.weight, self.position_embeddings.weight,
                                    self.token_type_embeddings.weight, None, b * n, n, self.LayerNorm, -1 if pad is None else pad)
-        return F.dropout(y.view(b, n, -1), self.dropout_p, self.training)
+        return dropout(y.view(b, n, -1), self.dropout_p, self.training)
 
 
 def _bert_init_weights(module, initializer_range):
@@ -660,11 +660,18 @@ class SAM4C(_HipModule):
             return 5
         return 6
 
+    def _input_encoder(self, feat, bbox, lin_a, ln_a, lin_b, ln_b, p_drop, n):
+        """dropout(LN(feat W^T + b) + LN(bbox W^T + b)) -> [B, n, D]: one autograd node, HIP kernels only (autograd.InputEncoderFn)"""
+        b = feat.shape[0]
+        out = InputEncoderFn.apply(lin_a.weight, feat.flatten(0, 1), bbox.flatten(0, 1), lin_a, ln_a, lin_b, ln_b,
+                                   float(p_drop) if self.training else 0.0, lin_a)
+        return out.view(b, n, -1)
+
     def _forward_obj_encoding(self, bd):
         feat = _pack_features([bd["pad_obj_features"]], self.normalize, 0)
-        x = (layer_norm(linear(feat, self.linear_obj_feat_to_mmt_in), self.obj_feat_layer_norm)
-             + layer_norm(linear(_pack_features([bd["pad_obj_bboxes"][:, :, :-1]], False, 0), self.linear_obj_bbox_to_mmt_in), self.obj_bbox_layer_norm))
-        x = F.dropout(x, self.obj_drop_p, self.training)
+        bbox = _pack_features([bd["pad_obj_bboxes"][:, :, :-1]], False, 0)
+        x = self._input_encoder(feat, bbox, self.linear_obj_feat_to_mmt_in, self.obj_feat_layer_norm, self.linear_obj_bbox_to_mmt_in, self.obj_bbox_layer_norm,
+                                self.obj_drop_p, feat.shape[1])
         bd["obj_mmt_in"] = GradBarrierFn.apply(x, "obj") if self.training and torch.is_grad_enabled() else x
 
     def _forward_ocr_encoding(self, bd):
@@ -672,9 +679,9 @@ class SAM4C(_HipModule):
         assert ft.size(-1) == 300 and ph.size(-1) == 604
         # FastText | PHOC | FRCN | 50 legacy all-zero order columns (sa_m4c.py:242), normalised and packed into the K-padded GEMM operand
         feat = _pack_features([ft, ph, fc] if self.mmt_config.use_phoc_fasttext else [fc], self.normalize, 50)
-        x = (layer_norm(linear(feat, self.linear_ocr_feat_to_mmt_in), self.ocr_feat_layer_norm)
-             + layer_norm(linear(_pack_features([bd["pad_ocr_bboxes"][:, :, :-1]], False, 0), self.linear_ocr_bbox_to_mmt_in), self.ocr_bbox_layer_norm))
-        x = F.dropout(x, self.ocr_drop_p, self.training)
+        bbox = _pack_features([bd["pad_ocr_bboxes"][:, :, :-1]], False, 0)
+        x = self._input_encoder(feat, bbox, self.linear_ocr_feat_to_mmt_in, self.ocr_feat_layer_norm, self.linear_ocr_bbox_to_mmt_in, self.ocr_bbox_layer_norm,
+                                self.ocr_drop_p, feat.shape[1])
         bd["ocr_mmt_in"] = GradBarrierFn.apply(x, "ocr") if self.training and torch.is_grad_enabled() else x
 
     def _forward_text_bert(self, bd):
@@ -708,11 +715,13 @@ class SAM4C(_HipModule):
             main.wait_stream(side)
             dyn.record_stream(main)
             bd["dynamic_ocr_scores"] = dyn
-            bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
+            if bd.get("_sam_want_scores", True):       # (the Trainer's loss reads the two blocks; it asks for no concatenated copy)
+                bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
             return
         bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
         bd["dynamic_ocr_scores"] = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
-        bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
+        if bd.get("_sam_want_scores", True) or not self.training:
+            bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
 
     def forward(self, batch_dict, use_beam_search=False):
         if use_beam_search:
@@ -751,7 +760,7 @@ class SAM4C(_HipModule):
                 self._forward_output(batch_dict)
                 batch_dict["train_prev_inds"][:, 1:] = batch_dict["scores"].argmax(dim=-1)[:, :-1]
             batch_dict.pop("_sam_decode_cache", None)
-        return {"textvqa_scores": batch_dict["scores"]}
+        return {"textvqa_scores": batch_dict.get("scores")}
 
     def get_optimizer_parameters(self, base_lr):
         """sa_m4c.py:349-371"""

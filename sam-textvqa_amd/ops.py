@@ -202,6 +202,16 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_drop
     return dx, (dxd if dxd is not None else (dx if want_dropped else None))
 
 
+def add_dropout(a, b, p_drop, seed=0, offset=0):
+    """dropout(a + b) -> bf16 [M, D] (b may be None: plain dropout, which is also its own backward on dy); hidden-state dropout stream"""
+    _chk(a, BF16, "a")
+    m, d = a.shape
+    out = torch.empty((m, d), dtype=BF16, device=a.device)
+    capi.call("sam_add_dropout_bf16", capi.ptr(a), a.stride(0), capi.ptr(b), 0 if b is None else b.stride(0), capi.ptr(out), out.stride(0), m, d,
+              float(p_drop), int(seed), int(offset), capi.stream_handle())
+    return out
+
+
 def colsum(x, out, accumulate=True):
     """out[n] (+)= sum_m x[m,n]  (x bf16 [M,N], out fp32 [N])"""
     m, n = x.shape

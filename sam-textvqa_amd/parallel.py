@@ -22,8 +22,15 @@ import torch.distributed as dist
 
 
 class GradReducer:
-    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0, scatter_fn=None, sparse_range=None):
+    def __init__(self, flat_grad, bucket_bytes=64 << 20, overlap=True, group=None, dense_lo=0, scatter_fn=None, sparse_range=None, payload=None):
         self.grad = flat_grad
+        # wire format of the dense buckets.  "fp32": one all-reduce per bucket.  "bf16" (SAM_GRAD_PAYLOAD=bf16): half the bytes on the links --
+        # all-to-all of bf16 slices (rank j receives slice j of every rank: on xGMI's fully connected point-to-point links every pair carries
+        # 1/W of the bucket at the same time), fp32 sum of the W slices on receipt, all-gather of the bf16-rounded sums.  Every rank ends
+        # with the same bits (each slice is summed by exactly one rank), the sum itself is rounded to bf16 once.
+        self.payload = payload or __import__("os").environ.get("SAM_GRAD_PAYLOAD", "fp32")
+        if self.payload not in ("fp32", "bf16"):
+            raise ValueError("GradReducer payload must be 'fp32' or 'bf16', not %r" % (self.payload,))
         self.scatter_fn = scatter_fn or _scatter_rows
         # [sparse_lo, sparse_hi) is exchanged through sparse_rows(), not all-reduced.  `dense_lo=k` is the short form of sparse_range=(0, k)
         # (two optimizer groups: the word-embedding table is the first parameter of flat storage); with the reference's three groups
@@ -119,6 +126,7 @@ class GradReducer:
         self.next_bucket = 0
         self.ready_lo = self.grad.numel()      # gradients at addresses >= ready_lo are final
         self.work = []
+        self._keep = []
         self.snapshots = []
         self.barrier_seen = set()
         self.done = [False] * len(self.regions)
@@ -138,12 +146,35 @@ class GradReducer:
                 self.stream.wait_stream(st)
             with torch.cuda.stream(self.stream):
                 if self.check:
-                    self.snapshots.append((k, chunk.clone()))
-                self.work.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self.snapshots.append((k, self._snapshot(chunk)))
+                self._exchange(chunk, True)
         else:
             if self.check:
-                self.snapshots.append((k, chunk.clone()))
-            dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group)
+                self.snapshots.append((k, self._snapshot(chunk)))
+            self._exchange(chunk, False)
+
+    def _snapshot(self, chunk):
+        """what a 1-rank exchange must leave in the bucket (SAM_REDUCER_CHECK): the bucket itself, bf16-rounded under the bf16 payload"""
+        return chunk.clone() if self.payload == "fp32" else chunk.to(torch.bfloat16).float()
+
+    def _exchange(self, chunk, async_op):
+        """sum `chunk` over the ranks, in place"""
+        if self.payload == "fp32":
+            w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                self.work.append(w)
+            return
+        W, n = self.world_size, chunk.numel()
+        per = (n + W - 1) // W
+        send = torch.zeros((W * per,), dtype=torch.bfloat16, device=chunk.device)
+        send[:n] = chunk                                               # fp32 -> bf16 (RNE), zero tail
+        recv = torch.empty_like(send)
+        dist.all_to_all_single(recv, send, group=self.group)           # recv[r * per : (r + 1) * per] = rank r's copy of MY slice
+        mine = recv.view(W, per).float().sum(dim=0).to(torch.bfloat16)  # fp32 accumulation over the ranks, in rank order
+        out = torch.empty_like(send)
+        dist.all_gather_into_tensor(out, mine, group=self.group)
+        chunk.copy_(out[:n])
+        self._keep.append((send, recv, mine, out))                     # (allocated on the caller's stream, used on the reducer's: held until finish())
 
     def region_done(self, lo):
         """everything at flat offsets >= lo has its final gradient: launch every bucket that is now complete"""
@@ -163,21 +194,34 @@ class GradReducer:
                 if int(cnt[0]) != -int(cnt[1]):
                     raise RuntimeError("GradReducer.sparse_rows: ranks hold different numbers of rows (%d..%d); pad the last batch" % (-int(cnt[1]), int(cnt[0])))
                 self._checked_rows = True
+            ids, rows = ids.contiguous(), rows.contiguous()
             ids_all = torch.empty((w * ids.numel(),), dtype=ids.dtype, device=ids.device)
             rows_all = torch.empty((w * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)
-            dist.all_gather_into_tensor(ids_all, ids.contiguous(), group=self.group)
-            dist.all_gather_into_tensor(rows_all, rows.contiguous(), group=self.group)
+            if self.overlap:
+                # gather + sort + scatter leave the compute stream: the table's rows are ready (enqueued) when this is called, whatever is
+                # left of the backward pass -- the object / OCR encoders' weight gradients -- runs next to the exchange; finish() joins
+                self._note_stream()
+                self.stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.stream):
+                    dist.all_gather_into_tensor(ids_all, ids, group=self.group)
+                    dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+                    self.scatter_fn(grad_table, ids_all, rows_all, padding_idx)
+                self._keep.append((ids, rows, ids_all, rows_all))
+                return
+            dist.all_gather_into_tensor(ids_all, ids, group=self.group)
+            dist.all_gather_into_tensor(rows_all, rows, group=self.group)
             ids, rows = ids_all, rows_all
         self.scatter_fn(grad_table, ids, rows, padding_idx)
 
     def finish(self):
         """after backward: reduce whatever is left, then make the compute stream wait for the exchange"""
+        self.late_buckets = len(self.buckets) - self.next_bucket        # buckets no finality mark released (0 when the regions tile the whole buffer)
         self.region_done(0)
         for w in self.work:
             w.wait()
         if self.overlap:
             torch.cuda.current_stream().wait_stream(self.stream)
-        self.work = []
+        self.work, self._keep = [], []
         for k, snap in self.snapshots:
             lo, hi = self.buckets[k]
             if not torch.equal(snap, self.grad[lo:hi]):

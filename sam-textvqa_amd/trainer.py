@@ -69,7 +69,7 @@ class Trainer:
           MMT / TextBert encoder layers -> EncoderLayerFn.backward of that layer;  TextBert position / type / LayerNorm -> EmbedLayerNormFn.backward;
           PrevPredEmbeddings, classifier, pointer net -> "head": when the gradients of all three MMT inputs are complete (GradBarrierFn: every
           node downstream of them, incl. the single-node PrevPredFn and the two nn.Linear heads, has run its backward).
-        Object / OCR encoders have no trigger (they leave at finish()); the word-embedding table is exchanged row-sparsely."""
+          object / OCR input encoders -> InputEncoderFn.backward;  the word-embedding table is exchanged row-sparsely."""
         model, flat = self.model, self.flat
         units = []
 
@@ -99,6 +99,19 @@ class Trainer:
                 def parameters():
                     return [emb.position_embeddings.weight, emb.token_type_embeddings.weight, emb.LayerNorm.weight, emb.LayerNorm.bias]
             add(_P, emb.LayerNorm)
+        # object / OCR input encoders: one autograd node each (InputEncoderFn), final when that node's backward returns; the region id hangs on
+        # the first of the four modules
+        for names in (("linear_ocr_feat_to_mmt_in", "ocr_feat_layer_norm", "linear_ocr_bbox_to_mmt_in", "ocr_bbox_layer_norm"),
+                      ("linear_obj_feat_to_mmt_in", "obj_feat_layer_norm", "linear_obj_bbox_to_mmt_in", "obj_bbox_layer_norm")):
+            mods = [getattr(model, n, None) for n in names]
+            if all(m is not None for m in mods):
+                class _E:
+                    _mods = mods
+
+                    @classmethod
+                    def parameters(cls):
+                        return [p for m in cls._mods for p in m.parameters()]
+                add(_E, mods[0])
         return units
 
     def _register_regions(self, reducer):
@@ -169,6 +182,7 @@ class Trainer:
             # is exactly the gradient of the global mean
             c_global = batch_dict["train_loss_mask"].to(device=flat.grad.device, dtype=torch.float32).sum().reshape(1)
             work = parallel.dist.all_reduce(c_global, group=self.reducer.group, async_op=True)
+        batch_dict["_sam_want_scores"] = False                   # the loss kernel reads the classifier / pointer blocks separately
         model(batch_dict)
         if work is not None:
             work.wait()

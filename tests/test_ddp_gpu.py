@@ -54,7 +54,7 @@ def _run(rank, world, port, out_dir):
     tr = Trainer(model, base_lr=1e-3, seed=3)
     assert (tr.reducer is not None) == (world > 1)
     if world > 1:
-        assert tr.reducer.world_size == world and tr.reducer.overlap and tr.reducer.dense_lo > 0 and len(tr.reducer.regions) == 5
+        assert tr.reducer.world_size == world and tr.reducer.overlap and tr.reducer.dense_lo > 0 and len(tr.reducer.regions) == 7
     losses = []
     per = 8 // world
     for step in range(STEPS):
@@ -101,3 +101,30 @@ def test_two_ranks_match_each_other_and_the_global_batch_run(tmp_path):
     cos = float(torch.dot(u_dp[moved], u_g[moved]) / (u_dp[moved].norm() * u_g[moved].norm()))
     rel = float((u_dp - u_g).norm() / u_g.norm())
     assert cos > 0.98 and rel < 0.2, (cos, rel)
+
+
+@pytest.mark.parametrize("payload", ["fp32", "bf16"])
+def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
+    """the command the driver uses on a multi-GPU node -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W` -- at N = 1 with the data-parallel machinery forced on (SAM_FORCE_DIST=1: RCCL
+    communicator, bucketed all-reduce on the reducer stream, row-sparse table exchange, global loss count) and every bucket re-verified at
+    finish() (SAM_REDUCER_CHECK=1).  The JSON line must carry the contract's fields and the exposed-communication figure."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAM_FORCE_DIST="1", SAM_REDUCER_CHECK="1", SAM_GRAD_PAYLOAD=payload, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
+    assert "exposed_comm_ms" in out and out["exposed_comm_ms"] >= 0.0

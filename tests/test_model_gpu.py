@@ -481,24 +481,28 @@ for dist_on in (True, False):
         assert red.sparse_hi - red.sparse_lo >= w.numel()
         assert all(hi <= red.sparse_lo or lo >= red.sparse_hi for lo, hi in red.buckets)            # the table is in no dense bucket
         # regions from the end: 2 MMT layers | PrevPredEmbeddings (barrier) | 1 TextBert layer | its embeddings | [table] | classifier + pointer net (barrier)
-        assert len(red.regions) == 6 and red.barrier_regions == [2, 5] and red.regions[4][0] == red.sparse_hi and red.regions[5][1] == red.sparse_lo
-        assert red.regions[5][0] == flat.range_of(model.ocr_ptr_net)[0] > flat.range_of(model.linear_ocr_feat_to_mmt_in)[0]
+        # | OCR input encoder | object input encoder -- down to offset 0: nothing is left for finish()
+        assert len(red.regions) == 8 and red.barrier_regions == [2, 5] and red.regions[4][0] == red.sparse_hi and red.regions[5][1] == red.sparse_lo
+        assert red.regions[5][0] == flat.range_of(model.ocr_ptr_net)[0] == red.regions[6][1]
+        assert red.regions[6][0] == flat.range_of(model.linear_ocr_feat_to_mmt_in)[0] == red.regions[7][1] and red.regions[7][0] == 0
     if dist_on and not three:
         w = model.text_bert.embeddings.word_embeddings.weight
         assert tr.reducer.dense_lo == tr.flat.layout[1][0] >= w.numel() > 0 and w._sam_sparse_reduce and tr.reducer.overlap
         assert min(lo for lo, _ in tr.reducer.buckets) == tr.reducer.dense_lo and tr.reducer.check
         red = tr.reducer
         # regions, from the end of the buffer down: 2 MMT layers | pointer net + classifier + PrevPredEmbeddings (barrier) | 1 TextBert layer | its embeddings
-        assert len(red.regions) == 5 and red.barrier_region == 2 and red.barrier_names == {"txt", "obj", "ocr"}
+        # | OCR input encoder | object input encoder, which ends where the row-sparse table begins
+        assert len(red.regions) == 7 and red.barrier_region == 2 and red.barrier_names == {"txt", "obj", "ocr"}
         assert red.regions[0][1] == tr.flat.numel and all(a[0] == b[1] for a, b in zip(red.regions[:-1], red.regions[1:]))
         assert red.regions[2] == (tr.flat.range_of(model.ocr_ptr_net)[0], tr.flat.range_of(model.mmt.encoder)[0])
         assert any(lo == red.regions[-1][0] for lo, _ in red.buckets)     # bucket boundary at the low end of the regions
-        assert red.regions[-1][0] > tr.flat.range_of(model.linear_ocr_feat_to_mmt_in)[0] > tr.flat.range_of(model.linear_obj_feat_to_mmt_in)[0] >= red.dense_lo
+        assert red.regions[-2][0] == tr.flat.range_of(model.linear_ocr_feat_to_mmt_in)[0] and red.regions[-1][0] == tr.flat.range_of(model.linear_obj_feat_to_mmt_in)[0] == red.dense_lo
     batch = make_batch(4, vocab=300, device="cuda", seed=21)
     batch["question_indices"] = batch["question_indices"] % 500
     losses = [tr.step(clone_batch(batch)).item() for _ in range(4)]
     if dist_on:
         assert all(tr.reducer.done) and tr.reducer.barrier_seen == {"txt", "obj", "ocr"}      # every finality mark fired during the last backward
+        assert tr.reducer.late_buckets == 0                                                   # ... and released every bucket before finish()
         red = tr.reducer                                     # the checker itself: release everything, then write late -> finish() must object
         red.begin_step(); red.region_done(0)
         tr.flat.grad[red.buckets[1][0] + 5] += 1.0

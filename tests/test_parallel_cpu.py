@@ -47,6 +47,41 @@ def test_grad_reducer_gloo_world2():
     assert res == [(0, True, 4), (1, True, 4)]
 
 
+def _bf16_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sam_textvqa_amd.parallel import GradReducer, init_distributed
+    init_distributed()
+    n = 1001                                                                      # not a multiple of the world size: padded slices
+    g = torch.Generator().manual_seed(7 + rank)
+    mine = torch.randn(n, generator=g)
+    grad = mine.clone()
+    red = GradReducer(grad, bucket_bytes=4 * 300, payload="bf16")
+    red.begin_step(); red.region_done(0); red.finish()
+    all_ = [torch.randn(n, generator=torch.Generator().manual_seed(7 + r)) for r in range(world)]
+    # what the wire format promises: every rank's contribution rounded to bf16, summed in fp32 in rank order, the sum rounded to bf16 once
+    expect = sum(a.to(torch.bfloat16).float() for a in all_).to(torch.bfloat16).float()
+    exact = sum(all_)
+    q.put((rank, torch.equal(grad, expect), float((grad - exact).abs().max() / exact.abs().max()), grad.double().sum().item()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_bf16_payload_gloo_world2():
+    """SAM_GRAD_PAYLOAD=bf16: all-to-all of bf16 slices + fp32 sum on receipt + all-gather; both ranks end with the same bits"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res[0][1] and res[1][1], res
+    assert res[0][2] < 2.0 ** -7 and res[0][3] == res[1][3], res                   # bf16-accurate, replicas bit-identical
+
+
 def test_single_process_reducer_is_noop():
     from sam_textvqa_amd.parallel import GradReducer
     g = torch.ones(10)
