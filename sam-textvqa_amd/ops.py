@@ -204,7 +204,9 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_drop
 
 def add_dropout(a, b, p_drop, seed=0, offset=0):
     """dropout(a + b) -> bf16 [M, D] (b may be None: plain dropout, which is also its own backward on dy); hidden-state dropout stream"""
-    _chk(a, BF16, "a")
+    for name, t in (("a", a), ("b", b)):
+        if t is not None and (not t.is_cuda or t.dtype != BF16 or t.dim() != 2 or t.stride(1) != 1):
+            raise capi.SamHipError("add_dropout: %s must be a bf16 [M, D] GPU tensor with unit column stride" % name)
     m, d = a.shape
     out = torch.empty((m, d), dtype=BF16, device=a.device)
     capi.call("sam_add_dropout_bf16", capi.ptr(a), a.stride(0), capi.ptr(b), 0 if b is None else b.stride(0), capi.ptr(out), out.stride(0), m, d,

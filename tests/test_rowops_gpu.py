@@ -175,3 +175,67 @@ def test_sorted_embedding_backward_is_deterministic_and_equals_index_add():
     keep = ids != 0
     ref.index_add_(0, ids[keep], dy[keep].double())
     assert (outs[0].double() - ref).abs().max().item() < 1e-4 and torch.equal(outs[0][0], base[0])
+
+
+def test_add_dropout_kernel_mask_scale_and_backward_consistency():
+    """sam_add_dropout_bf16 (object / OCR input-encoder dropout, sa_m4c.py:224,263): p = 0 is the bf16 sum; p > 0 drops ~p of the elements, scales
+    the kept ones by 1 / keep (keep probability quantised to 16 bits), and the backward (same kernel on dy, b = NULL) regenerates the SAME mask"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(1500, 768, generator=g).to(torch.bfloat16).cuda()
+    b = torch.randn(1500, 768, generator=g).to(torch.bfloat16).cuda()
+    ref = (a.float() + b.float())
+    out0 = ops.add_dropout(a, b, 0.0)
+    assert torch.equal(out0, ref.to(torch.bfloat16))
+    p = 0.1
+    out = ops.add_dropout(a, b, p, seed=11, offset=5)
+    kept = out != 0
+    frac = 1.0 - kept.float().mean().item()
+    assert abs(frac - p) < 0.003, frac
+    keep_q = 1.0 - round(p * 65536) / 65536.0
+    assert torch.equal(out[kept], (ref / keep_q).to(torch.bfloat16)[kept])
+    assert torch.equal(ops.add_dropout(a, b, p, seed=11, offset=5), out)                       # counter-based: same (seed, offset) -> same bits
+    assert not torch.equal(ops.add_dropout(a, b, p, seed=11, offset=6) != 0, kept)
+    ones = torch.ones_like(a)
+    mask = ops.add_dropout(ones, None, p, seed=11, offset=5)                                   # the backward pass applied to dy = 1
+    live = ref.to(torch.bfloat16) != 0
+    assert torch.equal((mask != 0) & live, kept & live)
+    assert torch.equal(mask[mask != 0].float(), torch.full_like(mask[mask != 0].float(), float(torch.tensor(1.0 / keep_q).to(torch.bfloat16))))
+    # strided rows (a column block of a wider buffer)
+    wide = torch.randn(64, 2304, generator=g).to(torch.bfloat16).cuda()
+    v = wide[:, 768:1536]
+    assert torch.equal(ops.add_dropout(v, None, 0.0), v)
+
+
+def test_input_encoder_node_matches_the_unfused_chain():
+    """InputEncoderFn = dropout(LN(feat W^T + b) + LN(bbox W^T + b)) as one autograd node: with dropout off, output and all eight parameter
+    gradients equal the chain of LinearFn / LayerNormFn nodes it replaces (same kernels, same order of accumulation)"""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.autograd import InputEncoderFn, layer_norm, linear
+    from sam_textvqa_amd.params import prepare
+    import torch.nn as nn
+
+    class Enc(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.la, self.na = nn.Linear(2048, 768), M.BertLayerNorm(768, eps=1e-12)
+            self.lb, self.nb = nn.Linear(4, 768), M.BertLayerNorm(768, eps=1e-12)
+    torch.manual_seed(0)
+    enc = Enc().cuda()
+    with torch.no_grad():
+        for ln in (enc.na, enc.nb):
+            ln.weight.add_(0.1 * torch.randn_like(ln.weight)); ln.bias.add_(0.1 * torch.randn_like(ln.bias))
+    fp = prepare(enc)
+    g = torch.Generator().manual_seed(1)
+    feat = torch.randn(300, 2048, generator=g).to(torch.bfloat16).cuda()
+    bbox = torch.zeros(300, 8, dtype=torch.bfloat16).cuda(); bbox[:, :4] = torch.rand(300, 4, generator=g).to(torch.bfloat16).cuda()
+    gout = torch.randn(300, 768, generator=g).to(torch.bfloat16).cuda()
+    fp.zero_grad()
+    y1 = layer_norm(linear(feat, enc.la), enc.na) + layer_norm(linear(bbox, enc.lb), enc.nb)
+    y1.backward(gout)
+    g1 = fp.grad.clone()
+    fp.zero_grad()
+    y2 = InputEncoderFn.apply(enc.la.weight, feat, bbox, enc.la, enc.na, enc.lb, enc.nb, 0.0, enc.la)
+    y2.backward(gout)
+    assert torch.equal(y1, y2)
+    assert torch.equal(g1, fp.grad)
