@@ -4,8 +4,8 @@
 The HIP path computes in bf16 (fp32 accumulate); the goldens are fp32.  Two checks per tensor:
   * vs the oracle run on the bf16-rounded weights/inputs (isolates kernel arithmetic from input rounding) and
   * vs the fp32 golden itself,
-both with a relative-to-max bound that grows with depth: every stored activation is re-rounded to bf16 (2^-9
-relative), so an L-op chain is allowed L * 2^-8; the per-kernel 1e-3 bound is enforced in the kernel tests."""
+both relative to max |ref|.  Every comparison prints the error it achieved (PARITY lines, `pytest -s`) and is bounded at about twice that
+(table `L` below): ~0.7 % for one layer, 1-2 % through six; the per-kernel 1e-3 bound is enforced in the kernel tests."""
 import os
 import numpy as np
 import pytest
