@@ -491,12 +491,16 @@ int launch8(GemmArgs a, int n_cu, hipStream_t st) {
   return SAM_OK;
 }
 
-// Tile choice.  Measured on the shapes of the step (M = 11648; tools/bench_gemm8.py, one box, both configurations forced in turn): what decides
-// is how well the tile count fills whole rounds of the chip's CUs, fill = tiles / (rounds * CUs), times the per-flop rate of the tile
-// (256x256 moves 1.3x fewer LDS bytes per flop: 1.36 vs 1.09 PFLOP/s on a full square problem).  N = 2304: fill 0.81 vs 0.95 -> 256 wins by 11 %;
-// N = 3072: 0.72 vs 0.95 -> tie; N = 768 (138 vs 244 tiles): 0.54 vs 0.95 -> 192 wins by 12 %.
-struct TileCfg { int bm, bn; float rate; };
-constexpr TileCfg kCfg[2] = {{256, 256, 1.30f}, {192, 192, 1.0f}};
+// Tile choice: a makespan model, calibrated with COLD operands (tools/bench_gemm_cold.py: every call on another buffer set, as in a training step,
+// where no activation is still in the Infinity Cache when it is needed; the cache-resident numbers of tools/bench_gemm8.py had put 192x192 ahead
+// on the wide outputs, which the step did not confirm).  A block runs `rounds` tiles back to back, each KT k-tiles of tk us plus an epilogue that
+// nothing overlaps (one block per CU) and that moves `streams` tile-sized bf16 operands (output, auxiliary output, residual / auxiliary
+// input) at es us each: time = rounds * (KT * tk + streams * es).  Measured: tk = 1.43 / 1.14 us (256^2 / 192^2), es = 6.0 / 4.7 us, and 7.2 us
+// per stream for the 192^2 tile when it writes two outputs (its 96-byte row segments per wave share 128-byte lines between waves).  The model is
+// within 6 % of the measurements on all seven encoder-layer shapes and picks the faster tile on each: 256^2 for N = 2304 / 3072 (FFN1 forward
+// 113 -> 88 us), 192^2 for N = 768 (138 tiles of 256^2 would leave half the chip idle).
+struct TileCfg { int bm, bn; float tk, es, es2; };
+constexpr TileCfg kCfg[2] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.7f, 7.2f}};
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int pick8(const GemmArgs& a, int tile, hipStream_t st) {
@@ -511,8 +515,10 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     if (tile != 0 && tile % 1000 != kCfg[c].bm) continue;        // 1192 / 1256: force the tile; 3192: 192x192 with the deferred epilogue (measured slower)
     const int tiles = ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn);
     const int rounds = (tiles + n_cu - 1) / n_cu;
-    const float useful = (float)a.M * (float)a.N / ((float)tiles * kCfg[c].bm * kCfg[c].bn);      // edge tiles compute rows / columns nobody stores
-    const float score = kCfg[c].rate * useful * (float)tiles / (float)(rounds * n_cu);
+    const bool two_out = EPI == SAM_EPI_BIAS_GELU_GRAD || EPI == SAM_EPI_BIAS_GELU;
+    const int streams = 1 + (two_out ? 1 : 0) + ((EPI == SAM_EPI_BIAS_DROPOUT_RES && a.residual) || EPI == SAM_EPI_MUL_AUX || EPI == SAM_EPI_DGELU ? 1 : 0);
+    const float t = (float)rounds * ((float)(a.K / BK) * kCfg[c].tk + (float)streams * (two_out ? kCfg[c].es2 : kCfg[c].es));
+    const float score = 1.0f / t;
     if (best < 0 || score > best_score) { best = c; best_score = score; }
   }
   if (best == 0) return launch8<256, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);

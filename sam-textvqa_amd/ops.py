@@ -411,4 +411,4 @@ def wgrad_grouped(jobs, force_tile=0):
         ws = _grouped_ws(jobs[0][0].device, int(capi.lib().sam_gemm_grouped_ws_bytes(arr, n)))
         arr[0].ws, arr[0].ws_bytes = ws.data_ptr(), ws.numel() * 4
     arr[0].force_tile = force_tile
-    capi.call("sam_gemm_bf16_grouped", arr, n, capi.stream_handle(), meta=dict(kernel="gemm_grouped_wgrad", flops=flops, shape=(n,)))
+    capi.call("sam_gemm_bf16_grouped", arr, n, capi.stream_handle(), meta=dict(kernel="gemm_grouped_wgrad", flops=flops, shape=(n, int(arr[0].K))))

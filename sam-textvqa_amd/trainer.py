@@ -260,6 +260,19 @@ class Trainer:
         self.global_step += 1
         return self._static_loss
 
+    def input_buffers(self):
+        """the captured step's own input tensors as a batch_dict (None before the capture).  A data pipeline that writes the next batch straight into
+        these (its host-to-device copies land here) hands `step()` tensors it recognises by address: no staging copy per input per step."""
+        if self._graph is None:
+            return None
+        bd = {}
+        for (k, kk, _), t in zip(self._graph_items, self._static_in):
+            if kk is None:
+                bd[k] = t
+            else:
+                bd.setdefault(k, {})[kk] = t
+        return bd
+
     def _capture(self, items, sig, dev):
         static_in = [torch.empty_like(v, device=dev).copy_(v) for _, _, v in items]
         static_bd = {}
@@ -286,6 +299,7 @@ class Trainer:
             ops.set_rng_state(None)                                           # the captured launches keep the pointer; eager launches go back to by-value
             dropout_clock.offset = saved_offset
         self._graph, self._graph_sig, self._static_in = g, sig, static_in
+        self._graph_items = [(k, kk, None) for k, kk, _ in items]
 
     def exposed_comm_ms(self):
         """mean GPU time of reducer.finish() (backward done -> every bucket reduced) over the steps run with measure_comm set"""
