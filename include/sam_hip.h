@@ -99,7 +99,8 @@ typedef struct sam_gemm_desc {
                          Partials go to `ws` and are summed in a fixed order (bit-reproducible, no atomics).  Two forms:
                          fp32 C + accumulate=1 + SAM_EPI_NONE (wgrad: the sum is added INTO C, bias_grad allowed), or any other
                          epilogue / output with accumulate=0 (skinny M, long K: the epilogue is applied by the reduction pass). */
-  float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] += sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad. */
+  float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] (+)= sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad;
+                         added to the old value when `accumulate`, overwritten otherwise (like C). */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
   int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height of the 4-wave kernels; 1192 / 1256: force the 8-wave
                          persistent kernel with 192x192 / 256x256 tiles (testing, tuning) */

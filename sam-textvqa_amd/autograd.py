@@ -382,10 +382,15 @@ class EncoderLayerFn(Function):
     def backward(ctx, dy):
         layer, p_hid, seeds = ctx.layer, ctx.p_hid, ctx.seeds
         att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+        # the Trainer marks a layer's twelve gradients "fresh" (not zeroed, nothing accumulated yet) at the start of a step: the first -- and in this
+        # model only -- backward through the layer then OVERWRITES them, which saves the zero-fill and the read half of every weight gradient's
+        # read-modify-write; without the mark (plain autograd use, gradient accumulation) everything accumulates as usual
+        acc = not getattr(layer, "_sam_grad_fresh", False)
+        layer._sam_grad_fresh = False
         if ctx.coarse:
             *saved, allow = ctx.saved_tensors
             dx = torchops.ns().encoder_layer_bwd(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch, att.num_attention_heads, ctx.scale,
-                                                 ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]))
+                                                 ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
             rid = getattr(layer, "_sam_region_id", None)
             if rid is not None and parallel.active_reducer is not None:
                 parallel.active_reducer.mark_done(rid)
@@ -396,7 +401,7 @@ class EncoderLayerFn(Function):
             dy = dy.to(BF16).contiguous()
         # ---- output block: y = LN(dropout(h W2^T + b2) + a)
         dz2, dy2 = ops.layernorm_bwd(dy, z2, mean2, rstd2, out.LayerNorm.weight, out.LayerNorm.weight.grad, out.LayerNorm.bias.grad,
-                                     dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1])
+                                     dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1], accumulate=acc)
         wgrads = [(dy2, h, out.dense.weight.grad, None)]          # the four weight gradients go out as ONE grouped launch at the end
         dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=pre)
         # ---- intermediate: h = gelu(a W1^T + b1)
@@ -404,13 +409,13 @@ class EncoderLayerFn(Function):
         da = ops.gemm(dpre, _w(inter.dense.weight), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz2)   # + residual path
         # ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
         dz1, dy1 = ops.layernorm_bwd(da, z1, mean1, rstd1, so.LayerNorm.weight, so.LayerNorm.weight.grad, so.LayerNorm.bias.grad,
-                                     dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1])
+                                     dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1], accumulate=acc)
         wgrads.append((dy1, ctxv, so.dense.weight.grad, None))
         dctx = ops.gemm(dy1, _w(so.dense.weight), b_kcontig=False)
         # ---- attention core + fused QKV projection
         dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn)
         wgrads.append((dqkv, x, dwqkv, dbqkv))
-        ops.wgrad_grouped(wgrads)
+        ops.wgrad_grouped(wgrads, accumulate=acc)
         dx = ops.gemm(dqkv, wqkv, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz1) if ctx.needs_input_grad[0] else None
         rid = getattr(layer, "_sam_region_id", None)
         if rid is not None and parallel.active_reducer is not None:

@@ -190,7 +190,7 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / WM) + tm * 16 + i;
-      if (m < p.M) bdst[m] = p.split_k > 1 ? accb[tm][0] : bdst[m] + accb[tm][0];
+      if (m < p.M) bdst[m] = (p.split_k > 1 || !p.accumulate) ? accb[tm][0] : bdst[m] + accb[tm][0];      // accumulate = 0: C and the bias gradient are overwritten
     }
   }
   void* Cout = p.C;

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
     gemm_epilogue8<TM, TN, SAM_EPI_NONE, float, RB, TM>(ea, acc, mw, nw, full, P.C, P.ldc, P.accumulate, i, g);
     if (do_bias && wc == 0)
       for (int r = lane; r < 128; r += 64)
-        if (mw + r < P.M) P.bias_grad[mw + r] += bsum[wr * 128 + r];
+        if (mw + r < P.M) P.bias_grad[mw + r] = (P.accumulate ? P.bias_grad[mw + r] : 0.f) + bsum[wr * 128 + r];
     return;
   }
   // ---- exchange: of every wave's TM row fragments this block keeps the half `half` (rows [64 half, 64 half + 64) of the wave's 128) and ships
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
     const int r = half * 64 + lane;
     if (mw + r < P.M) {
       const float a0 = bsum[wr * 128 + r], a1 = slot_load1(slot_in, 128 * 256 + wr * 64 + lane);
-      P.bias_grad[mw + r] += half == 0 ? a0 + a1 : a1 + a0;
+      P.bias_grad[mw + r] = (P.accumulate ? P.bias_grad[mw + r] : 0.f) + (half == 0 ? a0 + a1 : a1 + a0);
     }
   }
 }
@@ -271,7 +271,7 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   int tiles = 0, min_kt = 1 << 30;
   for (int q = 0; q < count; ++q) {
     const sam_gemm_desc* d = descs + q;
-    if (d->K % BK != 0 || d->M % 8 != 0 || d->N % 8 != 0 || (!d->accumulate && d->bias_grad)) return SAM_ERR_UNSUPPORTED;
+    if (d->K % BK != 0 || d->M % 8 != 0 || d->N % 8 != 0 ) return SAM_ERR_UNSUPPORTED;
     if ((int64_t)d->K * d->lda * 2 >= (int64_t)0x7fffffff || (int64_t)d->K * d->ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;
     WProb& p = w.p[q];
     p.A = (const bf16_t*)d->A; p.lda = d->lda; p.B = (const bf16_t*)d->B; p.ldb = d->ldb; p.C = (float*)d->C; p.ldc = d->ldc; p.bias_grad = d->bias_grad;

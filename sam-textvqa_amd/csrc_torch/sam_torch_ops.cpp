@@ -79,13 +79,13 @@ Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOp
 
 // dW += dy^T x (and db += colsum(dy)) for up to 8 jobs in one launch
 struct WgradJob { const Tensor* dy; const Tensor* x; const Tensor* dw; const Tensor* db; };
-void wgrad_grouped(const std::vector<WgradJob>& jobs) {
+void wgrad_grouped(const std::vector<WgradJob>& jobs, bool accumulate = true) {
   sam_gemm_desc d[8] = {};
   TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 8, "wgrad_grouped: 1..8 jobs");
   for (size_t q = 0; q < jobs.size(); ++q) {
     const WgradJob& j = jobs[q];
     d[q].M = (int32_t)j.dy->size(1); d[q].N = (int32_t)j.x->size(1); d[q].K = (int32_t)j.dy->size(0);
-    d[q].c_is_f32 = 1; d[q].accumulate = 1; d[q].epilogue = SAM_EPI_NONE;
+    d[q].c_is_f32 = 1; d[q].accumulate = accumulate ? 1 : 0; d[q].epilogue = SAM_EPI_NONE;
     d[q].A = j.dy->data_ptr(); d[q].lda = j.dy->stride(0); d[q].B = j.x->data_ptr(); d[q].ldb = j.x->stride(0);
     d[q].C = j.dw->data_ptr(); d[q].ldc = j.dw->stride(0);
     d[q].bias_grad = j.db ? (float*)j.db->data_ptr() : nullptr;
@@ -149,7 +149,7 @@ std::tuple<Tensor, Tensor, Tensor> ln_fwd(const Tensor& x, const Tensor& gamma, 
 
 // -> (dx, dx_dropped or undefined); dgamma / dbeta / dbias accumulated in place
 std::tuple<Tensor, Tensor> ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& mean, const Tensor& rstd, const Tensor& gamma, const Tensor& dgamma,
-                                  const Tensor& dbeta, const Tensor* dbias, bool want_dropped, double p_drop, int64_t seed, int64_t offset) {
+                                  const Tensor& dbeta, const Tensor* dbias, bool want_dropped, double p_drop, int64_t seed, int64_t offset, bool accumulate = true) {
   need2d(dy, "dy");
   const int64_t m = x.size(0), d = x.size(1);
   Tensor dx = at::empty({m, d}, dy.options());
@@ -157,7 +157,7 @@ std::tuple<Tensor, Tensor> ln_bwd(const Tensor& dy, const Tensor& x, const Tenso
   Tensor ws = at::empty({(sam_layernorm_bwd_ws_bytes((int)d) + 3) / 4}, dy.options().dtype(at::kFloat));
   ok(sam_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.scalar_type() == at::kFloat, x.stride(0), (const float*)mean.data_ptr(),
                        (const float*)rstd.data_ptr(), (const float*)gamma.data_ptr(), (int)m, (int)d, dx.data_ptr(), p(dxd), dx.stride(0), (float)p_drop,
-                       (uint64_t)seed, (uint64_t)offset, (float*)dgamma.data_ptr(), (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr, 1,
+                       (uint64_t)seed, (uint64_t)offset, (float*)dgamma.data_ptr(), (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr, accumulate ? 1 : 0,
                        (float*)ws.data_ptr(), cur_stream()),
      "sam_layernorm_bwd");
   return {dx, dxd.defined() ? dxd : (want_dropped ? dx : Tensor())};
@@ -192,14 +192,16 @@ std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::
 
 // grads: same order as params, fp32 views into the flat gradient buffer (accumulated in place).  Returns dx (undefined-size-0 when !need_dx).
 Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch, int64_t heads,
-                         double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx) {
+                         double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate) {
+  // accumulate = false: every one of the twelve gradients is OVERWRITTEN (each is written exactly once by this call) -- the caller then need not
+  // zero them before the backward pass, and the weight-gradient kernels skip the read half of their read-modify-write
   TORCH_CHECK(saved.size() == S_COUNT && params.size() == P_COUNT && grads.size() == P_COUNT, "encoder_layer_bwd: bad list sizes");
   Tensor dy = dy_in;
   if (dy.scalar_type() != at::kBFloat16 || !dy.is_contiguous()) dy = dy.to(at::kBFloat16).contiguous();
   const Tensor &x = saved[S_X], &qkv = saved[S_QKV], &ctx = saved[S_CTX], &lse2 = saved[S_LSE], &keep = saved[S_KEEP], &z1 = saved[S_Z1], &a = saved[S_A],
                &pre = saved[S_PRE], &h = saved[S_H], &z2 = saved[S_Z2];
   // ---- output block: y = LN(dropout(h W2^T + b2) + a)
-  auto [dz2, dy2] = ln_bwd(dy, z2, saved[S_MEAN2], saved[S_RSTD2], params[P_LN2W], grads[P_LN2W], grads[P_LN2B], &grads[P_B2], true, p_hid, seeds[4], seeds[5]);
+  auto [dz2, dy2] = ln_bwd(dy, z2, saved[S_MEAN2], saved[S_RSTD2], params[P_LN2W], grads[P_LN2W], grads[P_LN2B], &grads[P_B2], true, p_hid, seeds[4], seeds[5], accumulate);
   GemmOpt o;
   o.epilogue = SAM_EPI_MUL_AUX; o.aux_in = &pre;
   Tensor dpre = gemm(dy2, params[P_W2], true, false, o);
@@ -207,12 +209,12 @@ Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz2;
   Tensor da = gemm(dpre, params[P_W1], true, false, o);
   // ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
-  auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3]);
+  auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3], accumulate);
   Tensor dctx = gemm(dy1, params[P_WO], true, false, GemmOpt());
   // ---- attention core + fused QKV projection
   Tensor dqkv = attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
   const Tensor dw2 = grads[P_W2], dw1 = grads[P_W1], db1 = grads[P_B1], dwo = grads[P_WO], dwqkv = grads[P_WQKV], dbqkv = grads[P_BQKV];
-  wgrad_grouped({{&dy2, &h, &dw2, nullptr}, {&dpre, &a, &dw1, &db1}, {&dy1, &ctx, &dwo, nullptr}, {&dqkv, &x, &dwqkv, &dbqkv}});
+  wgrad_grouped({{&dy2, &h, &dw2, nullptr}, {&dpre, &a, &dw1, &db1}, {&dy1, &ctx, &dwo, nullptr}, {&dqkv, &x, &dwqkv, &dbqkv}}, accumulate);
   if (!need_dx) return at::empty({0}, x.options());
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz1;
   return gemm(dqkv, params[P_WQKV], true, false, o);
@@ -253,7 +255,7 @@ TORCH_LIBRARY(sam_hip, m) {
   m.def("encoder_layer_fwd(Tensor x, Tensor allow, Tensor[] params, int batch, int heads, float scale, float p_attn, float p_hid, int[] seeds, float eps1, "
         "float eps2) -> Tensor[]");
   m.def("encoder_layer_bwd(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
-        "float p_hid, int[] seeds, bool need_dx) -> Tensor");
+        "float p_hid, int[] seeds, bool need_dx, bool accumulate) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under the CUDA dispatch key)

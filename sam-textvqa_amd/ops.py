@@ -394,16 +394,16 @@ def _grouped_ws(device, nbytes):
     return buf
 
 
-def wgrad_grouped(jobs, force_tile=0):
+def wgrad_grouped(jobs, force_tile=0, accumulate=True):
     """jobs: list of (dy [R,M] bf16, x [R,N] bf16, dW fp32 [M,N] view, dbias fp32 [M] or None).  dW += dy^T x (and dbias += colsum(dy))
-    for all jobs in ONE launch (sam_gemm_bf16_grouped)."""
+    for all jobs in ONE launch (sam_gemm_bf16_grouped); accumulate=False: both are overwritten instead (no read of the old gradient)."""
     n = len(jobs)
     arr = (capi.GemmDesc * n)()
     flops = 0.0
     for d, (dy, x, dw, db) in zip(arr, jobs):
         d.M, d.N, d.K = dy.shape[1], x.shape[1], dy.shape[0]
         d.a_kcontig = d.b_kcontig = 0
-        d.c_is_f32, d.accumulate, d.epilogue = 1, 1, capi.EPI_NONE
+        d.c_is_f32, d.accumulate, d.epilogue = 1, int(bool(accumulate)), capi.EPI_NONE
         d.A, d.lda, d.B, d.ldb, d.C, d.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
         d.bias_grad = _dp(db)
         flops += 2.0 * d.M * d.N * d.K

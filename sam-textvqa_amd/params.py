@@ -114,8 +114,18 @@ class FlatParams:
         if any(p._version != v for p, v in zip(self.params, self._versions)):
             self.refresh_shadows()
 
-    def zero_grad(self):
-        self.grad.zero_()
+    def zero_grad(self, skip=None):
+        """zero the gradient buffer; `skip`: sorted, disjoint [lo, hi) ranges to leave alone (gradients their producers overwrite, Trainer)"""
+        if not skip:
+            self.grad.zero_()
+            return
+        pos = 0
+        for lo, hi in skip:
+            if lo > pos:
+                self.grad[pos:lo].zero_()
+            pos = max(pos, hi)
+        if pos < self.numel:
+            self.grad[pos:].zero_()
 
     def range_of(self, module):
         """[start, end) element range of the flat buffers covering `module`'s parameters (they are contiguous)"""

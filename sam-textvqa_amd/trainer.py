@@ -56,6 +56,21 @@ class Trainer:
             self.flat.refresh_shadows()
         if reducer is not None:
             self._register_regions(reducer)
+        # encoder layers (MMT + TextBert: two thirds of the parameters) have their gradients overwritten by their backward, not accumulated into
+        # zeroed memory (autograd.EncoderLayerFn); SAM_GRAD_OVERWRITE=0 restores zero-fill + accumulate
+        self._fresh_layers, self._fresh_ranges = [], []
+        if os.environ.get("SAM_GRAD_OVERWRITE", "1") != "0":
+            for lo, hi, trig in sorted(self._units()):
+                if trig is not None and trig != "head" and hasattr(trig, "attention") and hasattr(trig, "intermediate"):
+                    self._fresh_layers.append(trig)
+                    self._fresh_ranges.append((lo, hi))
+            merged = []
+            for lo, hi in self._fresh_ranges:
+                if merged and merged[-1][1] == lo:
+                    merged[-1] = (merged[-1][0], hi)
+                else:
+                    merged.append((lo, hi))
+            self._fresh_ranges = merged
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
         self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
@@ -170,7 +185,9 @@ class Trainer:
         model, flat = self.model, self.flat
         if not model.training:
             model.train()                                        # (recursing over ~160 modules costs 0.6 ms of host time: only when needed)
-        flat.zero_grad()
+        for layer in self._fresh_layers:
+            layer._sam_grad_fresh = True                         # EncoderLayerFn.backward overwrites these gradients: they are not zeroed
+        flat.zero_grad(self._fresh_ranges)
         if self.reducer is not None:
             self.reducer.begin_step()
         parallel.active_reducer = self.reducer

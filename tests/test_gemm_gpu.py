@@ -300,6 +300,22 @@ def test_grouped_wgrad_eight_wave_pair_exchange(R):
         assert b is None or float((b - j[3]).abs().max()) <= 2e-4 * (1.0 + float(j[3].abs().max()))
 
 
+@pytest.mark.parametrize("R,force", [(1024, 1256), (1024, 128), (1456, 0)])
+def test_grouped_wgrad_overwrite_equals_accumulate_into_zero(R, force):
+    """accumulate = False: dW and the fused bias gradient are overwritten -- bit-identical to accumulating into zeroed buffers, whatever was there before
+    (the Trainer leaves the encoder layers' gradients un-zeroed and lets their backward overwrite them).  Both grouped kernels."""
+    ops, capi = _mods()
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    jobs, _ = _wgrad_jobs(R, shapes)
+    zero = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in jobs]
+    ops.wgrad_grouped(zero, force_tile=force)
+    junk = [(dy, x, torch.full_like(dw, 7.5), None if db is None else torch.full_like(db, -3.0)) for dy, x, dw, db in jobs]
+    ops.wgrad_grouped(junk, force_tile=force, accumulate=False)
+    for a, b in zip(zero, junk):
+        assert torch.equal(a[2], b[2])
+        assert a[3] is None or torch.equal(a[3], b[3])
+
+
 def test_grouped_wgrad_eight_wave_ragged_and_unsplit():
     """tile edges (M, N multiples of 8 but not of 256), a single problem, and a problem set with too many tiles for pairs (one block per tile)"""
     ops, capi = _mods()

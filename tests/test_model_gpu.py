@@ -348,6 +348,33 @@ def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
     tr.load_model_state_dict({"module." + k: v for k, v in sd["model_state_dict"].items()})
 
 
+def test_overwritten_layer_gradients_equal_zero_fill_plus_accumulate(monkeypatch):
+    """the Trainer does not zero the encoder layers' gradients: their backward overwrites them (SAM_GRAD_OVERWRITE, default on).  Same gradients,
+    bit for bit, as zero-fill + accumulate on every encoder-layer parameter; same trajectory"""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    runs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAM_GRAD_OVERWRITE", mode)
+        model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+        tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=False)
+        assert bool(tr._fresh_ranges) == (mode == "1")
+        if mode == "1":
+            assert len(tr._fresh_layers) == 3                       # 2 MMT layers + 1 TextBert layer
+            tr.flat.grad.fill_(123.0)                                # whatever is in the buffer before the first step must not matter
+        losses = [tr.step(clone_batch(batch)).item() for _ in range(2)]
+        grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+        runs.append((losses, grads, tr.flat.flat.clone(), [id(l) for l in tr._fresh_layers]))
+    (l1, g1, p1, _), (l0, g0, p0, _) = runs
+    for n in g1:
+        if ".encoder.layer." in n or "_layers." in n:              # TextBert / MMT encoder layers: exact
+            assert torch.equal(g1[n], g0[n]), n
+    assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    assert (p1 - p0).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize("from_bert_base", [False, True])
 def test_checkpoint_dict_is_the_reference_layout_and_resumes_exactly(from_bert_base, tmp_path):
     """train.py:177-187: model_state_dict, optimizer_state_dict (torch.optim.Adam layout over the reference's param groups), warmup_scheduler_state_dict
