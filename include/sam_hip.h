@@ -132,6 +132,15 @@ int64_t sam_layernorm_bwd_ws_bytes(int D);
 int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int x_is_f32, int64_t ldx, const float* mean, const float* rstd,
                       const float* gamma, int M, int D, void* dx, void* dx_dropped, int64_t ldo, float p_drop, uint64_t seed, uint64_t offset,
                       float* dgamma, float* dbeta, float* dbias, int accumulate, float* ws, void* stream);
+/* Deferred finalize: with bit 2 set in `accumulate` (accumulate | 4) sam_layernorm_bwd leaves its per-block partial sums in ws (which must then be
+ * private to the call and stay alive) and launches no reduction; sam_layernorm_bwd_finalize_batch finishes up to any number of such calls in one
+ * launch per 32 (dgamma / dbeta / dbias (+)= column sums of the partial rows, fixed order).  rows = sam_layernorm_bwd_partial_rows(M). */
+typedef struct sam_ln_finalize_item {
+  const float* ws; int32_t rows; int32_t accumulate;
+  float* dgamma; float* dbeta; float* dbias;   /* dbias may be NULL */
+} sam_ln_finalize_item;
+int sam_layernorm_bwd_partial_rows(int M);
+int sam_layernorm_bwd_finalize_batch(const sam_ln_finalize_item* items, int count, int D, void* stream);
 /* bias gradients: out[n] (+)= sum_m x[m,n], x bf16 [M,N]; ws: sam_colsum_ws_bytes(N) */
 int64_t sam_colsum_ws_bytes(int N);
 int sam_colsum_bf16(const void* x, int64_t ldx, int M, int N, float* out, int accumulate, float* ws, void* stream);

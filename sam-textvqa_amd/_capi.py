@@ -43,6 +43,8 @@ SIGNATURES = {
     "sam_layernorm_fwd": [_vp, _i, _i64, _vp, _vp, _f, _i, _i, _vp, _i64, _vp, _vp, _vp],
     "sam_layernorm_bwd": [_vp, _i64, _vp, _i, _i64, _vp, _vp, _vp, _i, _i, _vp, _vp, _i64, _f, _u64, _u64, _vp, _vp, _vp, _i, _vp, _vp],
     "sam_layernorm_bwd_ws_bytes": [_i],
+    "sam_layernorm_bwd_partial_rows": [_i],
+    "sam_layernorm_bwd_finalize_batch": [C.c_void_p, _i, _i, _vp],
     "sam_colsum_ws_bytes": [_i],
     "sam_colsum_bf16": [_vp, _i64, _i, _i, _vp, _i, _vp, _vp],
     "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
@@ -64,10 +66,14 @@ SIGNATURES = {
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],
     "sam_set_rng_state": [_vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 
 _lib = None
+
+
+class LnFinalizeItem(C.Structure):
+    _fields_ = [("ws", _vp), ("rows", C.c_int32), ("accumulate", C.c_int32), ("dgamma", _vp), ("dbeta", _vp), ("dbias", _vp)]
 
 
 class SamHipError(RuntimeError):

@@ -401,7 +401,7 @@ class EncoderLayerFn(Function):
             dy = dy.to(BF16).contiguous()
         # ---- output block: y = LN(dropout(h W2^T + b2) + a)
         dz2, dy2 = ops.layernorm_bwd(dy, z2, mean2, rstd2, out.LayerNorm.weight, out.LayerNorm.weight.grad, out.LayerNorm.bias.grad,
-                                     dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1], accumulate=acc)
+                                     dbias=out.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1], accumulate=acc, may_defer=True)
         wgrads = [(dy2, h, out.dense.weight.grad, None)]          # the four weight gradients go out as ONE grouped launch at the end
         dpre = ops.gemm(dy2, _w(out.dense.weight), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=pre)
         # ---- intermediate: h = gelu(a W1^T + b1)
@@ -409,7 +409,7 @@ class EncoderLayerFn(Function):
         da = ops.gemm(dpre, _w(inter.dense.weight), b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz2)   # + residual path
         # ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
         dz1, dy1 = ops.layernorm_bwd(da, z1, mean1, rstd1, so.LayerNorm.weight, so.LayerNorm.weight.grad, so.LayerNorm.bias.grad,
-                                     dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1], accumulate=acc)
+                                     dbias=so.dense.bias.grad, want_dropped=True, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1], accumulate=acc, may_defer=True)
         wgrads.append((dy1, ctxv, so.dense.weight.grad, None))
         dctx = ops.gemm(dy1, _w(so.dense.weight), b_kcontig=False)
         # ---- attention core + fused QKV projection

@@ -233,6 +233,40 @@ __global__ __launch_bounds__(64 * FIN_RL) void partial_finalize_kernel(const flo
   }
 }
 
+// the same reduction for up to 32 LayerNorm backward calls in ONE launch (blockIdx.z = call): a training step runs 26 LayerNorm backwards, each of
+// which used to be followed by its own 6 us finalize launch; with SAM_LN_DEFER_FINALIZE they leave their partial rows in place and one launch at the
+// end of the backward pass finishes all of them (the parameter gradients are not needed before the optimizer)
+struct FinalizeBatch { const float* ws[32]; float* out[32][3]; int nrows[32]; int accumulate[32]; int D; };
+__global__ __launch_bounds__(64 * FIN_RL) void partial_finalize_batch_kernel(FinalizeBatch b) {
+  __shared__ float red[FIN_RL][64];
+  const int z = blockIdx.z, D = b.D;
+  float* out = b.out[z][blockIdx.y];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6, c = min((int)blockIdx.x * 64 + cx, D - 1);
+  const int nrows = b.nrows[z];
+  const int64_t stride = 3 * (int64_t)D;
+  const float* base = b.ws[z] + (int64_t)blockIdx.y * D + c;
+  float s = 0.f;
+  if (out) {
+    for (int r = ry; r < nrows; r += FIN_RL * 8) {
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = base[(int64_t)min(r + FIN_RL * u, nrows - 1) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (r + FIN_RL * u >= nrows) t[u] = 0.f;
+      s += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+    }
+  }
+  red[ry][cx] = s;
+  __syncthreads();
+  if (out && ry == 0 && (int)blockIdx.x * 64 + cx < D) {
+    float tot = 0.f;
+#pragma unroll
+    for (int u = 0; u < FIN_RL; ++u) tot += red[u][cx];
+    out[c] = b.accumulate[z] ? out[c] + tot : tot;
+  }
+}
+
 // ------------------------------------------------------------------------------------------ colsum
 constexpr int COLSUM_CHUNKS = 64;
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* x, int64_t ldx, int M, int N, float* ws) {
@@ -500,10 +534,31 @@ extern "C" int sam_layernorm_bwd(const void* dy, int64_t ldd, const void* x, int
                     : ln_bwd_dispatch<bf16_t>(nch, dim3(nblk), st, (const bf16_t*)dy, ldd, x, ldx, mean, rstd, gamma, M, D, (bf16_t*)dx, dxd, ldo, thr16, inv_keep, seed, offset, ws);
   if (rc) return rc;
   SAM_LAUNCH_CHECK();
+  if (accumulate & 4) return SAM_OK;      // deferred: the partial rows stay in ws for sam_layernorm_bwd_finalize_batch
   // dbias of the dense in front of this LN = column sums of the (dropout-masked) dx
   FinalizeOuts fo = {{dgamma, dbeta, dbias}, {0, D, 2 * (int64_t)D}};
-  partial_finalize_kernel<<<dim3((D + 63) / 64, dbias ? 3 : 2), dim3(64 * FIN_RL), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, fo, accumulate);
+  partial_finalize_kernel<<<dim3((D + 63) / 64, dbias ? 3 : 2), dim3(64 * FIN_RL), 0, st>>>(ws, nblk, 3 * (int64_t)D, D, fo, accumulate & 1);
   SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
+extern "C" int sam_layernorm_bwd_partial_rows(int M) { return min(LN_PARTIAL_BLOCKS, (M + 3) / 4); }
+
+extern "C" int sam_layernorm_bwd_finalize_batch(const sam_ln_finalize_item* items, int count, int D, void* stream) {
+  SAM_REQUIRE(items && count >= 1 && D > 0 && D % 4 == 0, "sam_layernorm_bwd_finalize_batch: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  for (int i0 = 0; i0 < count; i0 += 32) {
+    FinalizeBatch b = {};
+    const int n = min(32, count - i0);
+    b.D = D;
+    for (int i = 0; i < n; ++i) {
+      const sam_ln_finalize_item& it = items[i0 + i];
+      SAM_REQUIRE(it.ws && it.dgamma && it.dbeta && it.rows >= 1 && it.rows <= LN_PARTIAL_BLOCKS, "sam_layernorm_bwd_finalize_batch: item %d is malformed", i0 + i);
+      b.ws[i] = it.ws; b.out[i][0] = it.dgamma; b.out[i][1] = it.dbeta; b.out[i][2] = it.dbias; b.nrows[i] = it.rows; b.accumulate[i] = it.accumulate & 1;
+    }
+    partial_finalize_batch_kernel<<<dim3((D + 63) / 64, 3, n), dim3(64 * FIN_RL), 0, st>>>(b);
+    SAM_LAUNCH_CHECK();
+  }
   return SAM_OK;
 }
 

@@ -148,19 +148,59 @@ std::tuple<Tensor, Tensor, Tensor> ln_fwd(const Tensor& x, const Tensor& gamma, 
 }
 
 // -> (dx, dx_dropped or undefined); dgamma / dbeta / dbias accumulated in place
+// Deferred LayerNorm finalizes (include/sam_hip.h: sam_layernorm_bwd_finalize_batch): when switched on (set_ln_defer, by the Trainer for the span of
+// a backward pass) the LayerNorm backwards of the coarse encoder-layer op leave their partial sums in private workspaces queued here, and
+// ln_finalize_flush reduces all of them in one launch.  One queue per process (the backward pass runs on one thread at a time).
+struct LnQueue {
+  std::mutex mu;
+  bool defer = false;
+  int64_t D = 0;
+  std::vector<sam_ln_finalize_item> items;
+  std::vector<Tensor> keep;
+};
+LnQueue& ln_queue() { static LnQueue q; return q; }
+
 std::tuple<Tensor, Tensor> ln_bwd(const Tensor& dy, const Tensor& x, const Tensor& mean, const Tensor& rstd, const Tensor& gamma, const Tensor& dgamma,
-                                  const Tensor& dbeta, const Tensor* dbias, bool want_dropped, double p_drop, int64_t seed, int64_t offset, bool accumulate = true) {
+                                  const Tensor& dbeta, const Tensor* dbias, bool want_dropped, double p_drop, int64_t seed, int64_t offset, bool accumulate = true,
+                                  bool may_defer = false) {
   need2d(dy, "dy");
   const int64_t m = x.size(0), d = x.size(1);
   Tensor dx = at::empty({m, d}, dy.options());
   Tensor dxd = (want_dropped && p_drop > 0) ? at::empty({m, d}, dy.options()) : Tensor();
   Tensor ws = at::empty({(sam_layernorm_bwd_ws_bytes((int)d) + 3) / 4}, dy.options().dtype(at::kFloat));
+  LnQueue& q = ln_queue();
+  bool defer = false;
+  if (may_defer) {
+    std::lock_guard<std::mutex> lock(q.mu);
+    defer = q.defer && (q.items.empty() || q.D == d);
+    if (defer) {
+      q.D = d;
+      q.items.push_back({(const float*)ws.data_ptr(), (int32_t)sam_layernorm_bwd_partial_rows((int)m), accumulate ? 1 : 0, (float*)dgamma.data_ptr(),
+                         (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr});
+      q.keep.push_back(ws);
+    }
+  }
   ok(sam_layernorm_bwd(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.scalar_type() == at::kFloat, x.stride(0), (const float*)mean.data_ptr(),
                        (const float*)rstd.data_ptr(), (const float*)gamma.data_ptr(), (int)m, (int)d, dx.data_ptr(), p(dxd), dx.stride(0), (float)p_drop,
-                       (uint64_t)seed, (uint64_t)offset, (float*)dgamma.data_ptr(), (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr, accumulate ? 1 : 0,
-                       (float*)ws.data_ptr(), cur_stream()),
+                       (uint64_t)seed, (uint64_t)offset, (float*)dgamma.data_ptr(), (float*)dbeta.data_ptr(), dbias ? (float*)dbias->data_ptr() : nullptr,
+                       (accumulate ? 1 : 0) | (defer ? 4 : 0), (float*)ws.data_ptr(), cur_stream()),
      "sam_layernorm_bwd");
   return {dx, dxd.defined() ? dxd : (want_dropped ? dx : Tensor())};
+}
+
+void set_ln_defer(bool on) {
+  LnQueue& q = ln_queue();
+  std::lock_guard<std::mutex> lock(q.mu);
+  q.defer = on;
+}
+
+void ln_finalize_flush() {
+  LnQueue& q = ln_queue();
+  std::lock_guard<std::mutex> lock(q.mu);
+  if (q.items.empty()) return;
+  ok(sam_layernorm_bwd_finalize_batch(q.items.data(), (int)q.items.size(), (int)q.D, cur_stream()), "sam_layernorm_bwd_finalize_batch");
+  q.items.clear();
+  q.keep.clear();          // (the flush runs on the stream the partials were written on: stream order protects the workspaces)
 }
 
 // ---------------------------------------------------------------------------------------------------------------- coarse: one encoder layer
@@ -201,7 +241,7 @@ Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor
   const Tensor &x = saved[S_X], &qkv = saved[S_QKV], &ctx = saved[S_CTX], &lse2 = saved[S_LSE], &keep = saved[S_KEEP], &z1 = saved[S_Z1], &a = saved[S_A],
                &pre = saved[S_PRE], &h = saved[S_H], &z2 = saved[S_Z2];
   // ---- output block: y = LN(dropout(h W2^T + b2) + a)
-  auto [dz2, dy2] = ln_bwd(dy, z2, saved[S_MEAN2], saved[S_RSTD2], params[P_LN2W], grads[P_LN2W], grads[P_LN2B], &grads[P_B2], true, p_hid, seeds[4], seeds[5], accumulate);
+  auto [dz2, dy2] = ln_bwd(dy, z2, saved[S_MEAN2], saved[S_RSTD2], params[P_LN2W], grads[P_LN2W], grads[P_LN2B], &grads[P_B2], true, p_hid, seeds[4], seeds[5], accumulate, true);
   GemmOpt o;
   o.epilogue = SAM_EPI_MUL_AUX; o.aux_in = &pre;
   Tensor dpre = gemm(dy2, params[P_W2], true, false, o);
@@ -209,7 +249,7 @@ Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz2;
   Tensor da = gemm(dpre, params[P_W1], true, false, o);
   // ---- attention output block: a = LN(dropout(ctx Wo^T + bo) + x)
-  auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3], accumulate);
+  auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3], accumulate, true);
   Tensor dctx = gemm(dy1, params[P_WO], true, false, GemmOpt());
   // ---- attention core + fused QKV projection
   Tensor dqkv = attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
@@ -252,10 +292,17 @@ TORCH_LIBRARY(sam_hip, m) {
   m.def("spatial_attn_bwd(Tensor dout, Tensor qkv, Tensor lse2, Tensor allow, Tensor keep, int batch, int heads, float scale, float p_drop) -> Tensor");
   m.def("layernorm_fwd(Tensor x, Tensor gamma, Tensor beta, float eps) -> (Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor gamma) -> (Tensor, Tensor, Tensor)");
+  m.def("set_ln_defer(bool on) -> ()");
+  m.def("ln_finalize_flush() -> ()");
   m.def("encoder_layer_fwd(Tensor x, Tensor allow, Tensor[] params, int batch, int heads, float scale, float p_attn, float p_hid, int[] seeds, float eps1, "
         "float eps2) -> Tensor[]");
   m.def("encoder_layer_bwd(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
         "float p_hid, int[] seeds, bool need_dx, bool accumulate) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(sam_hip, CompositeExplicitAutograd, m) {      // no tensor arguments to dispatch on
+  m.impl("set_ln_defer", set_ln_defer);
+  m.impl("ln_finalize_flush", ln_finalize_flush);
 }
 
 TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under the CUDA dispatch key)

@@ -189,16 +189,43 @@ def layernorm_fwd(x, gamma, beta, eps):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_dropped=False, p_drop=0.0, seed=0, offset=0, accumulate=True):
-    """-> (dx bf16, dx_dropped bf16 or None); dgamma/dbeta/dbias (fp32 [D]) are accumulated in place"""
+class LnFinalizeQueue:
+    """deferred LayerNorm-backward finalizes of the per-kernel (ctypes) route: see sam_layernorm_bwd_finalize_batch in include/sam_hip.h.  The Trainer
+    switches deferral on for the span of a backward pass and flushes before the gradient norm; the C++ custom ops keep their own queue
+    (torch.ops.sam_hip.set_ln_defer / ln_finalize_flush)."""
+    defer = False
+    items = []      # (ws tensor, rows, accumulate, dgamma, dbeta, dbias, D)
+
+    @classmethod
+    def flush(cls):
+        if not cls.items:
+            return
+        by_d = {}
+        for it in cls.items:
+            by_d.setdefault(it[6], []).append(it)
+        for d, its in by_d.items():
+            arr = (capi.LnFinalizeItem * len(its))()
+            for a, (ws, rows, acc, dg, db, dbias, _) in zip(arr, its):
+                a.ws, a.rows, a.accumulate, a.dgamma, a.dbeta, a.dbias = ws.data_ptr(), rows, acc, dg.data_ptr(), db.data_ptr(), _dp(dbias)
+            capi.call("sam_layernorm_bwd_finalize_batch", arr, len(its), d, capi.stream_handle())
+        cls.items = []
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_dropped=False, p_drop=0.0, seed=0, offset=0, accumulate=True, may_defer=False):
+    """-> (dx bf16, dx_dropped bf16 or None); dgamma/dbeta/dbias (fp32 [D]) are accumulated in place (overwritten with accumulate=False).
+    may_defer: the parameter-gradient reduction may be left to LnFinalizeQueue.flush() when deferral is on"""
     _chk(dy, BF16, "dy")
     m, d = x.shape
     dx = torch.empty((m, d), dtype=BF16, device=x.device)
     dxd = torch.empty((m, d), dtype=BF16, device=x.device) if (want_dropped and p_drop > 0) else None
-    ws = _workspace(capi.call("sam_layernorm_bwd_ws_bytes", d), x.device, "ln")
+    defer = may_defer and LnFinalizeQueue.defer
+    nbytes = capi.call("sam_layernorm_bwd_ws_bytes", d)
+    ws = torch.empty(((nbytes + 3) // 4,), dtype=torch.float32, device=x.device) if defer else _workspace(nbytes, x.device, "ln")
     capi.call("sam_layernorm_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(x), int(x.dtype == torch.float32), x.stride(0), capi.ptr(mean), capi.ptr(rstd),
               capi.ptr(gamma), m, d, capi.ptr(dx), capi.ptr(dxd), dx.stride(0), float(p_drop), int(seed), int(offset), capi.ptr(dgamma), capi.ptr(dbeta),
-              capi.ptr(dbias), int(accumulate), capi.ptr(ws), capi.stream_handle())
+              capi.ptr(dbias), int(bool(accumulate)) | (4 if defer else 0), capi.ptr(ws), capi.stream_handle())
+    if defer:
+        LnFinalizeQueue.items.append((ws, int(capi.call("sam_layernorm_bwd_partial_rows", m)), int(bool(accumulate)), dgamma, dbeta, dbias, d))
     return dx, (dxd if dxd is not None else (dx if want_dropped else None))
 
 

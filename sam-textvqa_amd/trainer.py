@@ -71,6 +71,7 @@ class Trainer:
                 else:
                     merged.append((lo, hi))
             self._fresh_ranges = merged
+        self.defer_ln = os.environ.get("SAM_LN_DEFER_FINALIZE", "1") != "0"
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
         self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
@@ -159,6 +160,18 @@ class Trainer:
         if heads:
             reducer.set_barrier(("txt", "obj", "ocr"), heads)
 
+    def _set_ln_defer(self, on):
+        from . import torchops
+        ops.LnFinalizeQueue.defer = on
+        if torchops.enabled():
+            torchops.ns().set_ln_defer(on)
+
+    def _ln_flush(self):
+        from . import torchops
+        ops.LnFinalizeQueue.flush()
+        if torchops.enabled():
+            torchops.ns().ln_finalize_flush()
+
     def _sparse_table_range(self):
         """the word-embedding table's [lo, hi) in flat storage when it can be exchanged row-sparsely (parallel.GradReducer.sparse_rows):
         it must start its optimizer group's segment or the buffer, so that the dense ranges around it stay whole; else None"""
@@ -204,11 +217,23 @@ class Trainer:
         if work is not None:
             work.wait()
         loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, global_count=c_global)
-        loss.backward()
+        # the encoder layers' LayerNorm backwards leave their dgamma / dbeta / dbias partial sums in place; ONE launch reduces all of them after the
+        # backward pass (26 finalize launches of ~6 us each otherwise).  Not under a reducer: there a layer's gradients must be final when its
+        # region is marked.
+        defer_ln = self.defer_ln and self.reducer is None
+        if defer_ln:
+            self._set_ln_defer(True)
+        try:
+            loss.backward()
+        finally:
+            if defer_ln:
+                self._set_ln_defer(False)
         side = getattr(model, "_side_stream", None)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
         parallel.active_reducer = None
+        if defer_ln:
+            self._ln_flush()
         if self.reducer is not None:
             if self.measure_comm:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -375,6 +375,29 @@ def test_overwritten_layer_gradients_equal_zero_fill_plus_accumulate(monkeypatch
     assert (p1 - p0).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("coarse", ["1", "0"])
+def test_deferred_layernorm_finalize_is_bit_identical(monkeypatch, coarse):
+    """SAM_LN_DEFER_FINALIZE (default on): the encoder layers' LayerNorm backwards leave their partial sums in place and one batched launch reduces them
+    after the backward pass -- same summation order, so every gradient is bit-identical to the immediate finalize.  Both launch routes (C++ ops, ctypes)."""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    monkeypatch.setenv("SAM_COARSE_OPS", coarse)
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    grads = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("SAM_LN_DEFER_FINALIZE", mode)
+        model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+        tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=False)
+        assert tr.defer_ln == (mode == "1")
+        tr.step(clone_batch(batch))
+        grads.append({n: p.grad.clone() for n, p in model.named_parameters() if "LayerNorm" in n or n.endswith("dense.bias")})
+    assert len(grads[0]) > 10
+    for n in grads[0]:
+        if ".encoder.layer." in n or "_layers." in n:
+            assert torch.equal(grads[0][n], grads[1][n]), n
+
+
 @pytest.mark.parametrize("from_bert_base", [False, True])
 def test_checkpoint_dict_is_the_reference_layout_and_resumes_exactly(from_bert_base, tmp_path):
     """train.py:177-187: model_state_dict, optimizer_state_dict (torch.optim.Adam layout over the reference's param groups), warmup_scheduler_state_dict
