@@ -277,8 +277,13 @@ class Trainer:
             return self._eager_step(batch_dict)                  # another shape (last partial batch): eager, the graph stays valid for the usual one
         if self._graph is None:
             if not self._graph_warm:                             # first call: a normal eager step (lazy kernel attributes, workspaces, RCCL-free init)
-                self._graph_warm = True
-                return self._eager_step(batch_dict)
+                self._graph_warm = True                          # ... on the stream the capture will use: the per-stream workspace caches (exchange
+                self._cap_stream = torch.cuda.Stream()           # buffer of the grouped wgrad, LayerNorm scratch) are then filled before the capture
+                self._cap_stream.wait_stream(torch.cuda.current_stream())     # and their zero-fills do not become graph nodes
+                with torch.cuda.stream(self._cap_stream):
+                    loss = self._eager_step(batch_dict)
+                torch.cuda.current_stream().wait_stream(self._cap_stream)
+                return loss
             try:
                 self._capture(items, sig, dev)
             except Exception as e:                               # capture is an optimisation: never lose the run over it
@@ -332,7 +337,7 @@ class Trainer:
         torch.cuda.synchronize()
         ops.set_rng_state(self._rng_state)
         try:
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g, stream=self._cap_stream):
                 self._rng_state[1:2].add_(self.GRAPH_OFFSET_STRIDE)           # first node: fresh masks for this replay
                 bd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in static_bd.items()}
                 loss = self._eager_step(bd, sched_dev=self._sched_dev)
