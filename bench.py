@@ -57,6 +57,8 @@ def profile_step(trainer, batch):
     agg = {}
     for name, meta, e0, e1 in recs:
         key = meta.get("kernel", name)
+        if key.startswith("gemm<") and meta.get("shape"):
+            key += "@M=%d" % meta["shape"][0]             # MMT-size (11648 rows) and TextBert / head-size launches of one symbol are different regimes
         a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
         a["calls"] += 1
         a["ms"] += e0.elapsed_time(e1)
@@ -144,7 +146,7 @@ def roofline_from(agg):
     by_shape = [dict(kernel=k, shape=list(sh), calls=b["calls"], avg_us=round(1e3 * b["ms"] / b["calls"], 2), tflops=round(b["flops"] / (b["ms"] * 1e-3) / 1e12, 1))
                 for (k, sh), b in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])]
     extra["gemm_by_shape"] = by_shape[:16]
-    return roof, table[:12], extra
+    return roof, table[:16], extra
 
 
 def cpu_baseline(context, layers, vocab, budget_s=60.0, warmup=5, timed=10):
