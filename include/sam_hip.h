@@ -32,6 +32,10 @@ int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_l
 int sam_attn_words_per_row(int N);
 /* MMT.forward prefix-LM + causal decoder mask, sam/sa_m4c.py:805-844; TextBert padding mask :386-387 (n_dec=0).
  * key_valid u8 [B,n_enc] -> out u32 [B,1,n_enc+n_dec,NW] */
+/* question / object / OCR padding masks (int64, 0 = padded: the reference's batch_dict entries question_mask, pad_obj_mask, pad_ocr_mask) -> uint8:
+ * key_valid [B, T+No+Nc] (the MMT's key-padding row, sa_m4c.py:805-812), q8 [B,T] (TextBert's, :386), ocr8 [B,Nc] (OcrPtrNet's, :889).  One launch. */
+int sam_pack_masks_u8(const int64_t* question_mask, int T, const int64_t* obj_mask, int No, const int64_t* ocr_mask, int Nc, int B, uint8_t* key_valid,
+                      uint8_t* q8, uint8_t* ocr8, void* stream);
 int sam_mask_bits_prefix_lm(const uint8_t* key_valid, int B, int n_enc, int n_dec, int NW, uint32_t* out, void* stream);
 /* any additive [B,1,N,N] fp32 mask (0 / -10000) as SpatialBertLayer.forward receives it, sam/sa_m4c.py:453-455 */
 int sam_mask_bits_from_additive(const float* mask, int B, int N, int NW, uint32_t* out, void* stream);

@@ -63,6 +63,7 @@ SIGNATURES = {
     "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],
     "sam_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, _vp],
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
+    "sam_pack_masks_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],
     "sam_set_rng_state": [_vp],
 }

@@ -260,6 +260,27 @@ class PrevPredFn(Function):
         return None, g_ans, g_ocr, None, None, None
 
 
+class SeqRowsFn(Function):
+    """(OCR rows, decoder rows) of the MMT output [B, N, D] as two contiguous tensors -- what the classifier and the pointer network consume
+    (sa_m4c.py:270-278).  As plain slices autograd copies the decoder rows once per consumer and builds the gradient of `seq` from two zero-filled
+    [B, N, D] tensors and an add; here: two copies forward, one zero-fill and two copies backward."""
+
+    @staticmethod
+    def forward(ctx, seq, ocr0, n_ocr, n_dec):
+        ctx.cfg = (seq.shape, seq.dtype, ocr0, n_ocr, n_dec)
+        return seq[:, ocr0: ocr0 + n_ocr].contiguous(), seq[:, seq.shape[1] - n_dec:].contiguous()
+
+    @staticmethod
+    def backward(ctx, d_ocr, d_dec):
+        shape, dtype, ocr0, n_ocr, n_dec = ctx.cfg
+        d = torch.zeros(shape, dtype=dtype, device=d_ocr.device if d_ocr is not None else d_dec.device)
+        if d_ocr is not None:
+            d[:, ocr0: ocr0 + n_ocr] = d_ocr
+        if d_dec is not None:
+            d[:, shape[1] - n_dec:] = d_dec
+        return d, None, None, None
+
+
 class DropoutFn(Function):
     """element-wise dropout on bf16 rows with the library's counter-based stream (ops.add_dropout): forward and backward regenerate the same
     mask from (seed, offset), nothing is stored.  Replaces F.dropout (torch's own Philox stream + a saved mask) on the path."""

@@ -104,7 +104,31 @@ __global__ void spatial_kernel(const uint32_t* base, const int8_t* adj, int B, i
   for (int h = R; h < H; ++h) out[(((int64_t)b * H + h) * N + q) * NW + w] = base_bits;
 }
 
+// the three padding masks of a batch (int64 0 / non-zero, as the reference's collate emits them) -> the uint8 forms the kernels read, one launch:
+// key_valid [B, T + No + Nc] (MMT keys), q8 [B, T] (TextBert keys), ocr8 [B, Nc] (pointer-network columns)
+__global__ void pack_masks_kernel(const int64_t* q, int T, const int64_t* obj, int No, const int64_t* ocr, int Nc, int B, uint8_t* key_valid, uint8_t* q8, uint8_t* ocr8) {
+  const int n = T + No + Nc;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * n) return;
+  const int b = idx / n, c = idx - b * n;
+  uint8_t v;
+  if (c < T) { v = q[(int64_t)b * T + c] != 0; q8[b * T + c] = v; }
+  else if (c < T + No) v = obj[(int64_t)b * No + (c - T)] != 0;
+  else { v = ocr[(int64_t)b * Nc + (c - T - No)] != 0; ocr8[b * Nc + (c - T - No)] = v; }
+  key_valid[idx] = v;
+}
+
 }  // namespace
+
+extern "C" int sam_pack_masks_u8(const int64_t* question_mask, int T, const int64_t* obj_mask, int No, const int64_t* ocr_mask, int Nc, int B, uint8_t* key_valid,
+                                 uint8_t* q8, uint8_t* ocr8, void* stream) {
+  SAM_REQUIRE(question_mask && obj_mask && ocr_mask && key_valid && q8 && ocr8, "sam_pack_masks_u8: null pointer");
+  SAM_REQUIRE(B > 0 && T > 0 && No > 0 && Nc > 0, "sam_pack_masks_u8: bad shape");
+  const int total = B * (T + No + Nc);
+  pack_masks_kernel<<<dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(question_mask, T, obj_mask, No, ocr_mask, Nc, B, key_valid, q8, ocr8);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
 
 extern "C" int sam_mask_bits_prefix_lm(const uint8_t* key_valid, int B, int n_enc, int n_dec, int NW, uint32_t* out, void* stream) {
   SAM_REQUIRE(key_valid && out, "sam_mask_bits_prefix_lm: null pointer");

@@ -17,7 +17,7 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
 from .params import prepare
 from .registry import registry
 
@@ -379,7 +379,9 @@ class TextBert(_HipModule):
     def forward(self, batch_dict):
         self._ready()
         x = self.embeddings(batch_dict["question_indices"])
-        allow = AllowBits(ops.mask_bits_prefix_lm(batch_dict["question_mask"].to(torch.uint8).contiguous(), 0))
+        m8 = batch_dict.get("_sam_masks_u8")          # (key_valid, question, ocr) packed once per forward by SAM4C.forward
+        q8 = m8[1] if m8 is not None else batch_dict["question_mask"].to(torch.uint8).contiguous()
+        allow = AllowBits(ops.mask_bits_prefix_lm(q8, 0))
         return self.encoder(x, allow, head_mask=[None] * self.config.num_hidden_layers)[0]
 
 
@@ -505,8 +507,12 @@ class MMT(_HipModule):
         n_obj = batch_dict["pad_obj_mask"].size(-1)
         n_ocr = batch_dict["pad_ocr_mask"].size(-1)
         n_dec = dec_emb.size(1)
-        key_valid = torch.cat([batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"]], dim=1)
-        allow = AllowBits(ops.mask_bits_prefix_lm(key_valid.to(device=x.device, dtype=torch.uint8).contiguous(), n_dec))
+        m8 = batch_dict.get("_sam_masks_u8")
+        if m8 is not None:
+            key_valid = m8[0]
+        else:
+            key_valid = torch.cat([batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"]], dim=1).to(device=x.device, dtype=torch.uint8).contiguous()
+        allow = AllowBits(ops.mask_bits_prefix_lm(key_valid, n_dec))
         cache = batch_dict.get("_sam_decode_cache")
         if cache is not None and not torch.is_grad_enabled():
             return self._forward_cached(batch_dict, cache, x, allow, n_txt, n_obj, n_ocr, n_dec)
@@ -550,7 +556,8 @@ class OcrPtrNet(_HipModule):
             query_inputs = query_inputs.unsqueeze(1)
         q = linear(query_inputs.to(BF16), self.query)
         k = linear(key_inputs.to(BF16), self.key)
-        mask = attention_mask.to(device=q.device).ne(0).to(torch.uint8).contiguous()
+        mask = attention_mask if (attention_mask.dtype == torch.uint8 and attention_mask.is_cuda and attention_mask.is_contiguous()) \
+            else attention_mask.to(device=q.device).ne(0).to(torch.uint8).contiguous()
         s = PtrScoresFn.apply(q, k, mask, 1.0 / math.sqrt(self.query_key_size))
         return s.squeeze(1) if squeeze else s
 
@@ -700,7 +707,12 @@ class SAM4C(_HipModule):
         bd.update(self.mmt(bd, fixed_ans_emb=self.classifier.weight))
 
     def _forward_output(self, bd):
-        dec = bd["mmt_dec_output"]
+        dec, ocr_rows = bd["mmt_dec_output"], bd["mmt_ocr_output"]
+        if self.training and torch.is_grad_enabled():
+            seq = bd["mmt_seq_output"]
+            ocr_rows, dec = SeqRowsFn.apply(seq, seq.shape[1] - dec.shape[1] - ocr_rows.shape[1], ocr_rows.shape[1], dec.shape[1])
+        m8 = bd.get("_sam_masks_u8")
+        ocr_mask = m8[2] if m8 is not None else bd["pad_ocr_mask"]
         if self.training and self.overlap_text_bert and torch.is_grad_enabled():
             # the two heads are independent chains of small kernels (768 decoder rows): the pointer network runs on the side stream next to
             # the classifier, forward and (autograd replays the streams) backward
@@ -710,7 +722,7 @@ class SAM4C(_HipModule):
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                dyn = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
+                dyn = self.ocr_ptr_net(dec, ocr_rows, ocr_mask)
             bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
             main.wait_stream(side)
             dyn.record_stream(main)
@@ -719,7 +731,7 @@ class SAM4C(_HipModule):
                 bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
             return
         bd["fixed_scores"] = linear(dec, self.classifier, out_f32=True)
-        bd["dynamic_ocr_scores"] = self.ocr_ptr_net(dec, bd["mmt_ocr_output"], bd["pad_ocr_mask"])
+        bd["dynamic_ocr_scores"] = self.ocr_ptr_net(dec, ocr_rows, ocr_mask)
         if bd.get("_sam_want_scores", True) or not self.training:
             bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
 
@@ -727,6 +739,14 @@ class SAM4C(_HipModule):
         if use_beam_search:
             raise NotImplementedError("beam search is disabled upstream (train.py:222-225) and out of scope")
         self._ready()
+        if all(k in batch_dict for k in ("question_mask", "pad_obj_mask", "pad_ocr_mask")) and batch_dict["question_mask"].is_cuda:
+            batch_dict["_sam_masks_u8"] = ops.pack_masks(batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"])
+        try:
+            return self._forward_impl(batch_dict)
+        finally:
+            batch_dict.pop("_sam_masks_u8", None)
+
+    def _forward_impl(self, batch_dict):
         if self.training and self.overlap_text_bert:
             # TextBert (20 tokens/sample: 240-block grids, latency-bound) runs on a side stream underneath the object / OCR encoders; autograd
             # replays each node's backward on its forward stream, so its backward overlaps theirs too

@@ -27,6 +27,22 @@ def words_per_row(n):
 
 
 # ----------------------------------------------------------------------------- masks
+def pack_masks(question_mask, obj_mask, ocr_mask):
+    """the batch's three padding masks -> (key_valid uint8 [B, T+No+Nc], question uint8 [B,T], ocr uint8 [B,Nc]) in one launch"""
+    ms = []
+    for m in (question_mask, obj_mask, ocr_mask):
+        if not m.is_cuda:
+            raise capi.SamHipError("pack_masks: masks must live on the GPU")
+        ms.append(m.contiguous() if m.dtype == torch.int64 else m.ne(0).to(torch.int64).contiguous())
+    q, o, c = ms
+    b, t, no, nc = q.shape[0], q.shape[1], o.shape[1], c.shape[1]
+    kv = torch.empty((b, t + no + nc), dtype=torch.uint8, device=q.device)
+    q8 = torch.empty((b, t), dtype=torch.uint8, device=q.device)
+    c8 = torch.empty((b, nc), dtype=torch.uint8, device=q.device)
+    capi.call("sam_pack_masks_u8", capi.ptr(q), t, capi.ptr(o), no, capi.ptr(c), nc, b, capi.ptr(kv), capi.ptr(q8), capi.ptr(c8), capi.stream_handle())
+    return kv, q8, c8
+
+
 def mask_bits_prefix_lm(key_valid, n_dec):
     """key_valid: uint8 [B, n_enc] -> uint32 [B, 1, N, NW] (MMT prefix-LM/causal mask, sa_m4c.py:805-844)."""
     _chk(key_valid, torch.uint8, "key_valid")

@@ -189,3 +189,19 @@ def test_attention_error_paths():
         ops.attn_fwd(qkv, allow, 4, 12, 0.1)
     with pytest.raises(SamHipError):
         ops.attn_fwd(qkv.cpu(), allow, 4, 12, 0.1)
+
+
+def test_pack_masks_one_launch_equals_cat_and_cast():
+    """sam_pack_masks_u8: the batch's question / object / OCR padding masks (int64 as the reference's collate emits them, or any other dtype) -> the three
+    uint8 forms the kernels read"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(0)
+    q = (torch.rand(7, 20, generator=g) > 0.3).long().cuda()
+    o = (torch.rand(7, 100, generator=g) > 0.1).long().cuda()
+    c = (torch.rand(7, 50, generator=g) > 0.5).long().cuda()
+    c[3] = 0                                                             # a sample without OCR tokens
+    kv, q8, c8 = ops.pack_masks(q, o, c)
+    assert kv.dtype == torch.uint8 and torch.equal(kv, torch.cat([q, o, c], 1).to(torch.uint8))
+    assert torch.equal(q8, q.to(torch.uint8)) and torch.equal(c8, c.to(torch.uint8))
+    kv2, _, _ = ops.pack_masks(q.float() * 3.0, o.bool(), c.int())      # other dtypes, non-0/1 values: non-zero = valid
+    assert torch.equal(kv2, kv)
