@@ -106,8 +106,8 @@ typedef struct sam_gemm_desc {
   float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] (+)= sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad;
                          added to the old value when `accumulate`, overwritten otherwise (like C). */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
-  int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height of the 4-wave kernels; 1192 / 1256: force the 8-wave
-                         persistent kernel with 192x192 / 256x256 tiles (testing, tuning) */
+  int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height of the 4-wave kernels; 1192 / 1256 / 1448: force the 8-wave
+                         persistent kernel with 192x192 / 256x256 / 192x256 tiles (testing, tuning) */
   int32_t defer_reduce;  /* split-K only: 1 = leave the partials in ws and let the caller run sam_gemm_splitk_reduce (separately timeable) */
   int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
 } sam_gemm_desc;

@@ -497,10 +497,11 @@ int launch8(GemmArgs a, int n_cu, hipStream_t st) {
 // nothing overlaps (one block per CU) and that moves `streams` tile-sized bf16 operands (output, auxiliary output, residual / auxiliary
 // input) at es us each: time = rounds * (KT * tk + streams * es).  Measured: tk = 1.43 / 1.14 us (256^2 / 192^2), es = 6.0 / 4.7 us, and 7.2 us
 // per stream for the 192^2 tile when it writes two outputs (its 96-byte row segments per wave share 128-byte lines between waves).  The model is
-// within 6 % of the measurements on all seven encoder-layer shapes and picks the faster tile on each: 256^2 for N = 2304 / 3072 (FFN1 forward
-// 113 -> 88 us), 192^2 for N = 768 (138 tiles of 256^2 would leave half the chip idle).
+// within 6 % of the measurements on all seven encoder-layer shapes and picks the faster tile on each: 256^2 for N = 2304, 192 x 256 for N = 3072
+// (732 tiles = 2.86 rounds of 0.75-size tiles instead of 2.16 -> 3 rounds of full-size ones; 64 output columns per wave = whole 128-byte lines:
+// tk 1.27, es 4.9 / 5.9; FFN1 forward 113 -> 88 -> 81 us), 192^2 for N = 768 (138 tiles of 256^2 would leave half the chip idle).
 struct TileCfg { int bm, bn; float tk, es, es2; };
-constexpr TileCfg kCfg[2] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.7f, 7.2f}};
+constexpr TileCfg kCfg[3] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.7f, 7.2f}, {192, 256, 1.27f, 4.9f, 5.9f}};
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int pick8(const GemmArgs& a, int tile, hipStream_t st) {
@@ -511,8 +512,9 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   int best = -1; float best_score = 0.f;
-  for (int c = 0; c < 2; ++c) {
-    if (tile != 0 && tile % 1000 != kCfg[c].bm) continue;        // 1192 / 1256: force the tile; 3192: 192x192 with the deferred epilogue (measured slower)
+  for (int c = 0; c < 3; ++c) {
+    // 1192 / 1256 / 1448: force 192x192 / 256x256 / 192x256; 3192: 192x192 with the deferred epilogue (measured slower)
+    if (tile != 0 && (tile == 1448 ? c != 2 : (c == 2 || tile % 1000 != kCfg[c].bm))) continue;
     const int tiles = ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn);
     const int rounds = (tiles + n_cu - 1) / n_cu;
     const bool two_out = EPI == SAM_EPI_BIAS_GELU_GRAD || EPI == SAM_EPI_BIAS_GELU;
@@ -522,6 +524,7 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     if (best < 0 || score > best_score) { best = c; best_score = score; }
   }
   if (best == 0) return launch8<256, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);
+  if (best == 2) return launch8<192, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);
   if (best == 1) {
     // 192x192: the deferred-epilogue kernel whenever its LDS bias image fits and it has something to do per tile
     static int defer = -1;

@@ -289,7 +289,7 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&
   else gemm_epilogue8_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
 }
 
-// 8-wave persistent kernels (gemm8.hip).  tile: 0 = heuristic, 1192 / 1256 = force the 192x192 / 256x256 configuration.
+// 8-wave persistent kernels (gemm8.hip).  tile: 0 = heuristic, 1192 / 1256 / 1448 = force the 192x192 / 256x256 / 192x256 configuration.
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.
 int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
