@@ -153,10 +153,12 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
           for (int b = 0; b < TM; ++b) sacc += acc[a][b][0] + acc[a][b][1] + acc[a][b][2] + acc[a][b][3];
         if (sacc == 12345.678f) reinterpret_cast<bf16_t*>(p.C)[tid] = (bf16_t)1;
       } else if constexpr (TM * TN > 18) {     // 32 fragments per wave: two halves, so that the batched operand prefetch of the epilogue fits the register file
-        gemm_epilogue8<TM, TN, EPI, OutT, 0, RB>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
-        gemm_epilogue8<TM, TN, EPI, OutT, RB, TM>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
+        const int me = p.dbg == 2 ? 0 : m0;     // (dbg 2: every tile's epilogue lands on the first tile row -- the outputs stay in the L2, no HBM traffic)
+        gemm_epilogue8<TM, TN, EPI, OutT, 0, RB>(p, acc, me + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
+        gemm_epilogue8<TM, TN, EPI, OutT, RB, TM>(p, acc, me + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
       } else {
-        gemm_epilogue8<TM, TN, EPI, OutT>(p, acc, m0 + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
+        const int me = p.dbg == 2 ? 0 : m0;
+        gemm_epilogue8<TM, TN, EPI, OutT>(p, acc, me + wr * (BM / 2), n0 + wc * (BN / 4), full, p.C, p.ldc, p.accumulate, i, g);
       }
       kt = 0;
       if (++j < my_tiles) {

@@ -30,7 +30,8 @@ struct GemmArgs {
   float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
   int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
   int* split_used;    // host pointer: receives the split factor actually launched
-  int dbg;            // tuning experiments only (SAM_GEMM8_DBG): 1 = gemm8 kernels skip the epilogue (results are garbage)
+  int dbg;            // tuning experiments only (SAM_GEMM8_DBG; results are garbage): 1 = gemm8 kernels skip the epilogue, 2 = every tile's epilogue
+                      // lands on the first tile row (outputs / residual / auxiliary rows stay in the L2: the epilogue without its HBM traffic)
 };
 
 template <typename OutT> struct Store4;
