@@ -292,9 +292,13 @@ class Trainer:
                 ops.set_rng_state(None)
                 self.use_graph, self._graph = False, None
                 return self._eager_step(batch_dict)
-        for (k, kk, v), dst in zip(items, self._static_in):
-            if v.data_ptr() != dst.data_ptr():
-                dst.copy_(v, non_blocking=True)
+        stale = [(dst, v) for (k, kk, v), dst in zip(items, self._static_in) if v.data_ptr() != dst.data_ptr()]
+        if stale:                                                   # one multi-tensor copy per dtype instead of ~20 launches (a batch that
+            try:                                                    # already lives in input_buffers() needs none)
+                torch._foreach_copy_([d for d, _ in stale], [v if v.device == d.device else v.to(d.device, non_blocking=True) for d, v in stale])
+            except (RuntimeError, AttributeError):
+                for d, v in stale:
+                    d.copy_(v, non_blocking=True)
         lrs = self.current_lrs()
         t = self.global_step + 1
         host = self._sched_host
