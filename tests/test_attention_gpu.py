@@ -180,6 +180,31 @@ def test_attention_fwd_bwd(shape, spatial, p_drop):
     assert_close_bf16(dqkv, qkv_ref.grad, name="attn dqkv")
 
 
+@pytest.mark.parametrize("T", [1, 17, 193, 257, 384])
+def test_attention_sequence_length_edges(T):
+    """lengths around the template boundaries: one token, one key past a 16-key tile, the first lengths that need 16 and 24 key tiles (two-pass dQ,
+    8 waves per block), and the 384-key limit itself; key-padding mask with a fully padded sample, dropout on"""
+    ops = _ops()
+    B, H, hd = 3, 12, 64
+    valid = [T, max(1, T // 2), 1]
+    kvm = torch.from_numpy(C.pad_mask(valid, T))
+    base = ops.mask_bits_prefix_lm(kvm.to(torch.uint8).cuda(), 0)
+    allow = O.allow_mask(kvm, T, 0, 0, None, (), H)
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn(B * T, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B * T, H * hd, generator=g).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(hd)
+    out, lse2, keep_bits = ops.attn_fwd(qkv.cuda(), base, B, H, scale, 0.1, seed=77, offset=3)
+    keep = unpack_bits(keep_bits, T)
+    inv_keep = 1.0 / (1.0 - round(0.1 * 65536) / 65536.0)
+    qkv_ref = qkv.float().requires_grad_(True)
+    ref_out, _ = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
+    assert_close_bf16(out, ref_out, name="attn out T=%d" % T)
+    (ref_out * dout.float()).sum().backward()
+    dqkv = ops.attn_bwd(dout.cuda(), qkv.cuda(), lse2, base, keep_bits, B, H, scale, 0.1)
+    assert_close_bf16(dqkv, qkv_ref.grad, name="attn dqkv T=%d" % T)
+
+
 def test_attention_error_paths():
     ops = _ops()
     from sam_textvqa_amd._capi import SamHipError
@@ -189,6 +214,8 @@ def test_attention_error_paths():
         ops.attn_fwd(qkv, allow, 4, 12, 0.1)
     with pytest.raises(SamHipError):
         ops.attn_fwd(qkv.cpu(), allow, 4, 12, 0.1)
+    with pytest.raises(SamHipError):                     # 385 keys: past the single-pass limit of the fused kernel
+        ops.mask_bits_prefix_lm(torch.ones(2, 385, dtype=torch.uint8, device="cuda"), 0)
 
 
 def test_pack_masks_one_launch_equals_cat_and_cast():
