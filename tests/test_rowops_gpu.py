@@ -45,7 +45,8 @@ def test_layernorm_golden_primitives():
     assert_close_bf16(dx, torch.from_numpy(g["ln_dx"]), frac=6e-3, name="LN dx vs golden (bf16 gy)")
 
 
-@pytest.mark.parametrize("M,D,in_dtype", [(1000, 768, torch.bfloat16), (37, 768, torch.float32), (5, 3072, torch.bfloat16), (130, 256, torch.bfloat16)])
+@pytest.mark.parametrize("M,D,in_dtype", [(1000, 768, torch.bfloat16), (37, 768, torch.float32), (5, 3072, torch.bfloat16), (130, 256, torch.bfloat16),
+                                         (1, 8, torch.bfloat16), (3, 2048, torch.bfloat16), (2049, 768, torch.bfloat16)])      # one row, the widest row, one row past 512 x 4
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_layernorm_fwd_bwd(M, D, in_dtype, p_drop):
     ops, capi = _mods()
@@ -75,7 +76,7 @@ def test_layernorm_fwd_bwd(M, D, in_dtype, p_drop):
         z = ops.gemm(ones.cuda(), wsel.cuda(), epilogue=capi.EPI_BIAS_DROPOUT_RES, p_drop=p_drop, seed=5, offset=9).float().cpu()
         keep = z > 0
         inv = 1.0 / (1.0 - round(p_drop * 65536) / 65536.0)
-        assert abs(keep.float().mean().item() - (1 - p_drop)) < 0.02
+        assert M * D < 4096 or abs(keep.float().mean().item() - (1 - p_drop)) < 0.02          # (a statistic: not for the 8-element case)
         ref_dxd = torch.where(keep, xo.grad * inv, torch.zeros(()))
         assert_close_bf16(dxd, ref_dxd, name="dropped dx")
         assert_close_bf16(dbias, ref_dxd.sum(0), ulps=0, frac=2e-3, name="dbias (dropped)")
