@@ -602,8 +602,11 @@ extern "C" int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2
     default: return SAM_ERR_UNSUPPORTED;
   }
   SAM_LAUNCH_CHECK();
-  if (a.nkt <= 12) attn_bwd_dkdv_kernel<256><<<dim3(B * H), blk, lds2, st>>>(a);
-  else attn_bwd_dkdv_kernel<512><<<dim3(B * H), blk, lds2, st>>>(a);
+  // dK / dV: 59 KB of LDS per block at 12 key tiles = two blocks per CU, so the 768 (batch, head) blocks of a B = 64 step take one and a half rounds;
+  // with 8 waves per block (1.5 key tiles per wave instead of 3) the half-empty second round runs at two waves per SIMD instead of one:
+  // dq + dkdv 87 -> 77 us (tools/bench_attn.py).  Short sequences (TextBert's 20 tokens = 2 key tiles) have nothing for 8 waves to do.
+  if (a.nkt < 8) attn_bwd_dkdv_kernel<256><<<dim3(B * H), dim3(256), lds2, st>>>(a);
+  else attn_bwd_dkdv_kernel<512><<<dim3(B * H), dim3(512), lds2, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
