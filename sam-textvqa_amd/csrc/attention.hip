@@ -84,9 +84,10 @@ struct AttnArgs {
 // --------------------------------------------------------------------------------------------
 // Long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU: those launches use
 // 8 waves per block (two per SIMD) instead of 4 -- with one wave per SIMD nothing hides the MFMA -> softmax -> MFMA dependency chain
-// (stress shape, B = 32: forward 88.7 us, backward 252 us at 4 waves).
+// (stress shape, B = 32: forward 88.7 us, backward 252 us at 4 waves).  The forward also runs 8 waves at 12 key tiles (two blocks = 16 waves per CU
+// instead of three blocks = 12: 34.1 -> 31.2 us with dropout at B = 64); the dQ kernel does not gain from it (77 -> 80 us) and stays at 4.
 template <int NKT>
-__global__ __launch_bounds__(NKT <= 12 ? 256 : 512, NKT <= 12 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPAD = NKT * 16;
   unsigned char* Ks = smem;
@@ -512,7 +513,7 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once = true;
   }
-  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(NKT <= 12 ? 256 : 512), lds, st>>>(a);
+  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(NKT <= 8 ? 256 : 512), lds, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
