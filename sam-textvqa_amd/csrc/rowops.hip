@@ -293,6 +293,13 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* x, in
 
 // ------------------------------------------------------------------------------------------ BCE loss
 // loss = sum_{r,c} bce(x, t) * mask[r] / max(sum(mask), 1);  d x = (sigmoid(x) - t) * mask[r] * gscale / count
+// One block row of the grid per decoding row r (no index division), two adjacent columns per thread (8-byte accesses: V and the row strides are
+// even, so a pair never straddles the classifier / pointer boundary); exp and log through the hardware units.  (The first version went element by
+// element with a 64-bit division and libm's log1pf per element: 39 us for 3.9 M scores, now ~12.)
+__device__ __forceinline__ float softplus_neg_abs(float e) {      // log(1 + e), e = exp(-|x|) in (0, 1]
+  return e < 1e-3f ? e * (1.0f - e * (0.5f - e * 0.33333334f)) : __logf(1.0f + e);
+}
+template <int VEC>      // 2: adjacent column pairs (everything even and 8-byte aligned); 1: any shape
 __global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ldf, const float* ocr, int64_t ldoc, const float* targets, int64_t ldt,
                                                   const float* mask, int R, int V, int No, float gscale, const float* global_count, float* loss,
                                                   bf16_t* d_fixed, int64_t lddf, float* d_ocr, int64_t lddo) {
@@ -308,22 +315,52 @@ __global__ __launch_bounds__(256) void bce_kernel(const float* fixed, int64_t ld
   cnt = fmaxf(global_count ? global_count[0] : sred[0] + sred[1] + sred[2] + sred[3], 1.0f);
   __syncthreads();
   const float inv_cnt = 1.0f / cnt;
-  const int W = V + No;
-  float acc = 0.f;
-  const int64_t total = (int64_t)R * W;
-  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-    const int r = idx / W, c = idx - (int64_t)r * W;
-    const float m = mask[r];
-    const float x = c < V ? fixed[(int64_t)r * ldf + c] : ocr[(int64_t)r * ldoc + (c - V)];
-    const float t = targets[(int64_t)r * ldt + c];
-    const float e = __expf(-fabsf(x));
-    acc += m * (fmaxf(x, 0.f) - x * t + log1pf(e));
-    const float sig = x >= 0.f ? 1.0f / (1.0f + e) : e / (1.0f + e);
-    const float gx = (sig - t) * m * inv_cnt * gscale;
-    if (c < V) d_fixed[(int64_t)r * lddf + c] = f2bf(gx);
-    else d_ocr[(int64_t)r * lddo + (c - V)] = gx;
+  const int W = V + No, r = blockIdx.x;
+  const float m = mask[r];
+  const float gs = m * inv_cnt * gscale;
+  if (m == 0.f) {                    // a masked decoding step (about half of them): zero gradient, nothing for the loss
+    for (int c = VEC * (blockIdx.y * 256 + threadIdx.x); c < W; c += VEC * 256 * gridDim.y) {
+      if (VEC == 2) {
+        if (c < V) *reinterpret_cast<unsigned*>(d_fixed + (int64_t)r * lddf + c) = 0u;
+        else *reinterpret_cast<float2*>(d_ocr + (int64_t)r * lddo + (c - V)) = make_float2(0.f, 0.f);
+      } else {
+        if (c < V) d_fixed[(int64_t)r * lddf + c] = (bf16_t)0;
+        else d_ocr[(int64_t)r * lddo + (c - V)] = 0.f;
+      }
+    }
+    return;
   }
-  acc = wave_sum(acc);
+  float acc = 0.f;
+  for (int c = VEC * (blockIdx.y * 256 + threadIdx.x); c < W; c += VEC * 256 * gridDim.y) {
+    const bool in_fixed = c < V;
+    float xs[2] = {0.f, 0.f}, ts[2] = {0.f, 0.f};
+    if (VEC == 2) {
+      const float2 x2 = in_fixed ? *reinterpret_cast<const float2*>(fixed + (int64_t)r * ldf + c) : *reinterpret_cast<const float2*>(ocr + (int64_t)r * ldoc + (c - V));
+      const float2 t2 = *reinterpret_cast<const float2*>(targets + (int64_t)r * ldt + c);
+      xs[0] = x2.x; xs[1] = x2.y; ts[0] = t2.x; ts[1] = t2.y;
+    } else {
+      xs[0] = in_fixed ? fixed[(int64_t)r * ldf + c] : ocr[(int64_t)r * ldoc + (c - V)];
+      ts[0] = targets[(int64_t)r * ldt + c];
+    }
+    float gx[2];
+#pragma unroll
+    for (int e_ = 0; e_ < VEC; ++e_) {
+      const float x = xs[e_], t = ts[e_];
+      const float e = __expf(-fabsf(x));
+      acc += fmaxf(x, 0.f) - x * t + softplus_neg_abs(e);
+      const float inv = __builtin_amdgcn_rcpf(1.0f + e);
+      const float sig = x >= 0.f ? inv : e * inv;
+      gx[e_] = (sig - t) * gs;
+    }
+    if (VEC == 2) {
+      if (in_fixed) *reinterpret_cast<unsigned*>(d_fixed + (int64_t)r * lddf + c) = pack_bf16x2(gx[0], gx[1]);
+      else *reinterpret_cast<float2*>(d_ocr + (int64_t)r * lddo + (c - V)) = make_float2(gx[0], gx[1]);
+    } else {
+      if (in_fixed) d_fixed[(int64_t)r * lddf + c] = f2bf(gx[0]);
+      else d_ocr[(int64_t)r * lddo + (c - V)] = gx[0];
+    }
+  }
+  acc = wave_sum(acc * m);
   if (lane == 0) sred[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) atomicAdd(loss, (sred[0] + sred[1] + sred[2] + sred[3]) * inv_cnt);
@@ -583,10 +620,18 @@ extern "C" int sam_bce_loss(const float* fixed_scores, int64_t ld_fixed, const f
   hipStream_t st = (hipStream_t)stream;
   hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), st);
   if (e != hipSuccess) { sam_set_error("sam_bce_loss: memset: %s", hipGetErrorString(e)); return (int)e; }
-  const int64_t total = (int64_t)R * (V + No);
-  const int blocks = (int)min((int64_t)2048, (total + 255) / 256);
-  bce_kernel<<<dim3(blocks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, global_count, loss,
-                                                 (bf16_t*)d_fixed, ld_dfixed, d_ocr, ld_docr);
+  const bool pairs = V % 2 == 0 && No % 2 == 0 && ld_fixed % 2 == 0 && ld_ocr % 2 == 0 && ld_t % 2 == 0 && ld_dfixed % 2 == 0 && ld_docr % 2 == 0 &&
+                     ((uintptr_t)fixed_scores % 8 == 0) && ((uintptr_t)ocr_scores % 8 == 0) && ((uintptr_t)targets % 8 == 0) && ((uintptr_t)d_ocr % 8 == 0) &&
+                     ((uintptr_t)d_fixed % 4 == 0);
+  const int per = pairs ? 2 : 1;
+  // one fp32 atomic per block lands on `loss`: keep the block count near 1-2 k (6144 blocks spent 60 us queueing on that one address)
+  const int chunks = max(1, min(min(8, 1024 / R), ((V + No + per - 1) / per + 255) / 256));
+  if (pairs)
+    bce_kernel<2><<<dim3(R, chunks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, global_count, loss,
+                                                         (bf16_t*)d_fixed, ld_dfixed, d_ocr, ld_docr);
+  else
+    bce_kernel<1><<<dim3(R, chunks), dim3(256), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, targets, ld_t, loss_mask, R, V, No, grad_scale, global_count, loss,
+                                                         (bf16_t*)d_fixed, ld_dfixed, d_ocr, ld_docr);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
