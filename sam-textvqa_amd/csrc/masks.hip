@@ -9,6 +9,7 @@
 //                                 emits it) + quadrant zeroing, AND-ed with the base bits
 // Bit k of word w of row (b,h,q) <=> key 32*w+k is visible.  Keys >= N always read 0.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -104,6 +105,55 @@ __global__ void spatial_kernel(const uint32_t* base, const int8_t* adj, int B, i
   for (int h = R; h < H; ++h) out[(((int64_t)b * H + h) * N + q) * NW + w] = base_bits;
 }
 
+// The same result with ONE WAVE per (batch, query) row and one key per lane: the row's relation bytes (n_oo x R, contiguous) are read in coalesced
+// 12-byte-per-lane pieces and every head's 64 key bits come out of a ballot.  (The kernel above gives each (row, word) to one thread, which walks
+// 32 keys on its own: 64 lanes, 64 cache lines per load -- 51 us per batch at B = 64 for 17 MB of relation bytes; this one ~12.)
+__global__ __launch_bounds__(256) void spatial_wave_kernel(const uint32_t* base, const int8_t* adj, int B, int N, int NW, int T, int n_oo, int R, int H,
+                                                           unsigned quadrant_bits, uint32_t* out) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B * N) return;
+  const int b = row / N, q = row - b * N;
+  const int rq = region_of(q, T, n_oo);
+  const uint32_t* brow = base + (int64_t)row * NW;
+  for (int c = 0; c * 64 < N; ++c) {                       // 64 keys per pass = two words of every head
+    const int key = c * 64 + lane;
+    unsigned bits = 0;                                      // bit h: key visible for head h
+    if (key < N) {
+      const int rk = region_of(key, T, n_oo);
+      const bool zeroed = (quadrant_bits >> (3 * rq + rk + 1)) & 1u;
+      if (!zeroed) {
+        if (rq == 1 && rk == 1) {
+          const int8_t* p = adj + (((int64_t)b * n_oo + (q - T)) * n_oo + (key - T)) * R;
+          if ((R & 3) == 0) {
+            const uint32_t* pw = reinterpret_cast<const uint32_t*>(p);
+            for (int j = 0; 4 * j < R; ++j) {
+              const uint32_t d = pw[j];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) bits |= (((d >> (8 * e)) & 0xffu) != 0 ? 1u : 0u) << (4 * j + e);
+            }
+          } else {
+            for (int h = 0; h < R; ++h) bits |= (p[h] != 0 ? 1u : 0u) << h;
+          }
+        } else {
+          bits = 0xffffu;
+        }
+      }
+    }
+    const int w0 = 2 * c;
+    const uint32_t b0 = w0 < NW ? brow[w0] : 0u, b1 = w0 + 1 < NW ? brow[w0 + 1] : 0u;
+    unsigned long long mine = ~0ull;                         // lane h ends up with head h's 64 key bits (heads >= R: no spatial restriction)
+    for (int h = 0; h < R; ++h) {
+      const unsigned long long m = __ballot((bits >> h) & 1u);
+      if (lane == h) mine = m;
+    }
+    for (int h = lane; h < H; h += 64) {                     // one store instruction for all heads
+      uint32_t* o = out + (((int64_t)b * H + h) * N + q) * NW;
+      if (w0 < NW) o[w0] = b0 & (uint32_t)mine;
+      if (w0 + 1 < NW) o[w0 + 1] = b1 & (uint32_t)(mine >> 32);
+    }
+  }
+}
+
 // the three padding masks of a batch (int64 0 / non-zero, as the reference's collate emits them) -> the uint8 forms the kernels read, one launch:
 // key_valid [B, T + No + Nc] (MMT keys), q8 [B, T] (TextBert keys), ocr8 [B, Nc] (pointer-network columns)
 __global__ void pack_masks_kernel(const int64_t* q, int T, const int64_t* obj, int No, const int64_t* ocr, int Nc, int B, uint8_t* key_valid, uint8_t* q8, uint8_t* ocr8) {
@@ -166,7 +216,10 @@ extern "C" int sam_mask_bits_spatial(const uint32_t* base, const int8_t* adj, in
   // legal quadrant ids are 1,2,4,7,8,9 (sa_m4c.py:505-549 raises ValueError on 3,5,6)
   SAM_REQUIRE((quadrant_bits & ~((1u << 1) | (1u << 2) | (1u << 4) | (1u << 7) | (1u << 8) | (1u << 9))) == 0, "sam_mask_bits_spatial: illegal quadrant id in 0x%x", quadrant_bits);
   const int64_t total = (int64_t)B * N * NW;
-  spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(base, adj, B, N, NW, T, n_oo, R, H, quadrant_bits, out);
+  static int wave_form = -1;
+  if (wave_form < 0) { const char* e = getenv("SAM_MASK_SPATIAL_WAVE"); wave_form = e ? atoi(e) : 1; }
+  if (wave_form) spatial_wave_kernel<<<dim3((unsigned)((B * N + 3) / 4)), dim3(256), 0, (hipStream_t)stream>>>(base, adj, B, N, NW, T, n_oo, R, H, quadrant_bits, out);
+  else spatial_kernel<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream>>>(base, adj, B, N, NW, T, n_oo, R, H, quadrant_bits, out);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
