@@ -62,6 +62,39 @@ __global__ __launch_bounds__(256) void l2norm_pack_kernel(const float* x, int64_
   for (int c = col0 + D + lane; c < zero_upto; c += 64) orow[c] = 0;
 }
 
+// rows of up to 2048 values: the whole row in registers (all of its loads in flight at once, one pass over memory); unconditional loads at clamped
+// chunk indices, as in the LayerNorm kernels
+template <int NCH>
+__global__ __launch_bounds__(256) void l2norm_pack_reg_kernel(const float* x, int64_t ldx, int M, int D, int normalize, float eps, bf16_t* out, int64_t ldo,
+                                                              int col0, int zero_upto) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (int64_t)row * ldx;
+  bf16_t* orow = out + (int64_t)row * ldo;
+  const int nchunk = D >> 2;
+  float v[NCH][4];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) ld4f(xr + 4 * min(lane + 64 * j, nchunk - 1), v[j]);
+  float scale = 1.f;
+  if (normalize) {
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+      if (lane + 64 * j < nchunk) q += (v[j][0] * v[j][0] + v[j][1] * v[j][1]) + (v[j][2] * v[j][2] + v[j][3] * v[j][3]);
+    scale = 1.0f / fmaxf(sqrtf(wave_sum(q)), eps);       // x / max(||x||, eps)
+  }
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[j][e] *= scale;
+      st4bf(orow + col0 + 4 * c, v[j]);
+    }
+  }
+  for (int c = col0 + D + lane; c < zero_upto; c += 64) orow[c] = 0;
+}
+
 // out[r, :] = table[ids[r], :] (bf16 rows, optional) + pos[r % S, :] + tt[type[r], :]   (fp32 out: the LayerNorm input)
 __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(const bf16_t* table, int64_t ld_table, const int64_t* ids, int table_rows, const float* pos,
                                                             int64_t ld_pos, int S, const float* tt, int64_t ld_tt, const uint8_t* type_ids, int n_types,
@@ -218,7 +251,13 @@ extern "C" int sam_l2norm_pack_bf16(const float* x, int64_t ldx, int M, int D, i
   SAM_REQUIRE(M > 0 && D > 0 && col0 >= 0 && col0 + D <= ldo && zero_upto <= ldo, "sam_l2norm_pack_bf16: need col0 + D <= ldo (M=%d D=%d col0=%d ldo=%ld)", M, D, col0,
               (long)ldo);
   const bool vec = D % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && col0 % 4 == 0 && ((uintptr_t)x % 16) == 0 && ((uintptr_t)out % 8) == 0;
-  if (vec)
+  const int nch = (D / 4 + 63) / 64;
+  const dim3 grid((M + 3) / 4), blk(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec && nch <= 2) l2norm_pack_reg_kernel<2><<<grid, blk, 0, st>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
+  else if (vec && nch <= 4) l2norm_pack_reg_kernel<4><<<grid, blk, 0, st>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
+  else if (vec && nch <= 8) l2norm_pack_reg_kernel<8><<<grid, blk, 0, st>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
+  else if (vec)
     l2norm_pack_kernel<<<dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
   else   // unaligned / odd-width rows (box coordinates): scalar accesses
     l2norm_pack_scalar_kernel<<<dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream>>>(x, ldx, M, D, normalize, eps, (bf16_t*)out, ldo, col0, zero_upto);
