@@ -385,6 +385,44 @@ __global__ __launch_bounds__(256) void ptr_fwd_kernel(const bf16_t* q, const bf1
     if (lane == 0) out[(int64_t)b * ldo_b + (int64_t)s * ldo_s + o] = acc * scale + (mask[(int64_t)b * No + o] ? 0.f : -10000.0f);
   }
 }
+// The same scores on the matrix cores: one block (4 waves) per sample; S <= 16 decoding rows x No <= 64 OCR columns = four 16 x 16 tiles; every wave
+// takes a quarter of D (6 k-steps of 32 at D = 768) with all of its fragment loads -- straight from global memory, rows are k-contiguous -- in flight
+// at once, and the four partial tiles are added in a fixed order through 16 KB of LDS.  (The dot-product kernel above: 19 us for 38 k scores.)
+template <int KS>        // k-steps of 32 per wave
+__global__ __launch_bounds__(256) void ptr_fwd_mfma_kernel(const bf16_t* q, const bf16_t* k, const uint8_t* mask, int S, int No, int D, float scale, float* out,
+                                                           int64_t ldo_b, int64_t ldo_s) {
+  __shared__ __attribute__((aligned(16))) float part[4][4][64][4];       // [wave][tile][lane][r]
+  const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, g = lane >> 4;
+  const bf16_t* qrow = q + ((int64_t)b * S + min(i, S - 1)) * D + wave * (KS * 32) + 8 * g;
+  bf16x8 qf[KS], kf[4][KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bf16_t* krow = k + ((int64_t)b * No + min(16 * t + i, No - 1)) * D + wave * (KS * 32) + 8 * g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8*>(krow + 32 * ks);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], acc, 0, 0, 0);      // D[o = 4g + r][s = i]
+    *reinterpret_cast<f32x4*>(&part[wave][t][lane][0]) = acc;
+  }
+  __syncthreads();
+  const int t = wave;                                    // wave t finishes tile t
+  const f32x4 a0 = *reinterpret_cast<const f32x4*>(&part[0][t][lane][0]), a1 = *reinterpret_cast<const f32x4*>(&part[1][t][lane][0]),
+              a2 = *reinterpret_cast<const f32x4*>(&part[2][t][lane][0]), a3 = *reinterpret_cast<const f32x4*>(&part[3][t][lane][0]);
+  if (i < S) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int o = 16 * t + 4 * g + r;
+      if (o < No) out[(int64_t)b * ldo_b + (int64_t)i * ldo_s + o] = ((a0[r] + a1[r]) + (a2[r] + a3[r])) * scale + (mask[(int64_t)b * No + o] ? 0.f : -10000.0f);
+    }
+  }
+}
+
 // dq[b,s,:] = scale * sum_o ds[b,s,o] k[b,o,:] ; dk[b,o,:] = scale * sum_s ds[b,s,o] q[b,s,:]   (one block per output row)
 __global__ __launch_bounds__(256) void ptr_bwd_kernel(const float* ds, int64_t ld_b, int64_t ld_s, const bf16_t* q, const bf16_t* k, int S, int No, int D,
                                                       float scale, bf16_t* dq, bf16_t* dk) {
@@ -640,7 +678,10 @@ extern "C" int sam_ptr_scores_fwd(const void* q, const void* k, const uint8_t* o
                                   int64_t ld_out_b, int64_t ld_out_s, void* stream) {
   SAM_REQUIRE(q && k && ocr_mask && out, "sam_ptr_scores_fwd: null pointer");
   SAM_REQUIRE(B > 0 && S > 0 && No > 0 && D > 0 && D % 4 == 0, "sam_ptr_scores_fwd: bad shape");
-  ptr_fwd_kernel<<<dim3(B, S), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
+  if (S <= 16 && No <= 64 && D == 768 && ((uintptr_t)q % 16) == 0 && ((uintptr_t)k % 16) == 0)      // the model's shape: matrix cores
+    ptr_fwd_mfma_kernel<6><<<dim3(B), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
+  else
+    ptr_fwd_kernel<<<dim3(B, S), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)q, (const bf16_t*)k, ocr_mask, S, No, D, scale, out, ld_out_b, ld_out_s);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -115,11 +115,12 @@ def test_bce_loss_matches_reference_loss(R, V, No):
     assert loss0.item() == 0.0 and (d0 == 0).all()
 
 
-def test_ptr_scores_golden_shapes():
+@pytest.mark.parametrize("S,No,D", [(12, 50, 768), (30, 100, 768), (5, 7, 64)])      # the model's shape (matrix-core kernel); the stress shape and a small one (dot-product kernel)
+def test_ptr_scores_golden_shapes(S, No, D):
     ops, _ = _mods()
-    B, S, No, D = 3, 12, 50, 768
+    B = 3
     q, k = rnd((B, S, D), 11), rnd((B, No, D), 12)
-    mask = torch.from_numpy(C.pad_mask([50, 0, 17], No))
+    mask = torch.from_numpy(C.pad_mask([No, 0, No // 3], No))
     scale = 1.0 / math.sqrt(D)
     qo, ko = q.float().requires_grad_(True), k.float().requires_grad_(True)
     ref = qo @ ko.transpose(-1, -2) * scale + ((1.0 - mask.float()) * -10000.0).unsqueeze(1)     # sa_m4c.py:891-893
