@@ -19,3 +19,19 @@ for b in (1, 64):
     torch.cuda.synchronize()
     t_all = (time.perf_counter() - t0) / n
     print("batch %2d: host returns after %.2f ms per step, step incl. GPU %.2f ms  (coarse ops %s)" % (b, t_host * 1e3, t_all * 1e3, os.environ.get("SAM_COARSE_OPS", "1")))
+# the captured step (one hipGraph replay per step): what the host pays then
+for b in (1, 64):
+    model_g = build_model(3, ("n", "n", "s", "s", "s", "s"), 5000)
+    trg = Trainer(model_g, seed=1, use_graph=True)
+    batch = make_batch(b, device="cuda", seed=1)
+    for _ in range(5): trg.step(clone_batch(batch))
+    staged = trg.input_buffers() or batch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 40
+    for _ in range(n): trg.step(clone_batch(staged))
+    t_host = (time.perf_counter() - t0) / n
+    torch.cuda.synchronize()
+    t_all = (time.perf_counter() - t0) / n
+    print("batch %2d, captured step: host returns after %.2f ms per step, step incl. GPU %.2f ms" % (b, t_host * 1e3, t_all * 1e3))
+    del trg, model_g
