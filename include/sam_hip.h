@@ -9,7 +9,11 @@
  *   - calls enqueue on `stream` (a hipStream_t; NULL = default stream) and never synchronise;
  *   - return 0 on success, a negative SAM_ERR_* for rejected arguments, a positive hipError_t for launch
  *     failures; sam_last_error() gives the thread-local message.  No exceptions cross the boundary.
- *   - stateless and re-entrant (one lazily-set function attribute per kernel is the only global state).
+ *   - re-entrant; the process-global state is: one lazily-set function attribute per kernel, the CU count of each device (cached on first use),
+ *     and the optional device-side dropout state installed by sam_set_rng_state (below) -- a pointer every later launch of the process reads.
+ *   - dropout everywhere is COUNTER-BASED (no generator object): a 32-bit integer hash ("lowbias32" finaliser, csrc/common.h) of
+ *     (seed, offset, row, column group); forward and backward regenerate identical bits from the same (seed, offset).  It is not Philox and
+ *     not torch's stream: masks are compared with the oracle through the exported keep bits / regenerated masks, never bit-for-bit with torch.
  */
 #ifndef SAM_HIP_H
 #define SAM_HIP_H
@@ -58,7 +62,7 @@ int sam_spatial_relation_tensor(const double* boxes, int B, int N, int context, 
  * qkv bf16 [B*N, 3*H*64] (q|k|v, straight out of the fused QKV projection); allow as above with element strides
  * (allow_stride_h = 0 broadcasts one mask over heads); out bf16 [B*N, H*64]; lse2 f32 [B,H,N] = log2-domain
  * logsumexp of scale*q.k (+inf for fully masked rows, whose output is exactly 0 as sa_m4c.py:574-584);
- * keep u32 [B,H,N,NW] receives the dropout keep bits when p_drop > 0 (Philox4x32-10 keyed by seed/offset). */
+ * keep u32 [B,H,N,NW] receives the dropout keep bits when p_drop > 0 (counter hash of (seed, offset, row, 32-key word)). */
 int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
                  int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
                  uint32_t* keep, void* stream);
@@ -86,7 +90,7 @@ int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uin
  *   SAM_EPI_BIAS_GELU_GRAD    aux_out = gelu_erf'(acc + bias) ; C = gelu_erf(acc + bias)     BertIntermediate in TRAINING: the derivative shares the
  *                             exponential with the activation (two extra FMAs); the backward then needs no transcendental at all:
  *   SAM_EPI_MUL_AUX           C = acc * aux_in[m,n]                               backward of BertIntermediate from the stored derivative
- * bias may be NULL (treated as 0); dropout uses Philox4x32-10 on (row, col/8) so the backward regenerates it. */
+ * bias may be NULL (treated as 0); dropout draws 8 x 16 bits per (row, col/8) from the counter hash so the backward regenerates it. */
 enum { SAM_EPI_NONE = 0, SAM_EPI_BIAS = 1, SAM_EPI_BIAS_GELU = 2, SAM_EPI_BIAS_DROPOUT_RES = 3, SAM_EPI_DGELU = 4, SAM_EPI_BIAS_GELU_GRAD = 5, SAM_EPI_MUL_AUX = 6 };
 typedef struct sam_gemm_desc {
   int32_t M, N, K;
@@ -119,7 +123,9 @@ int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);
 /* Workspace of the grouped call.  With descs[0].ws / ws_bytes >= this many bytes (16-byte aligned, ZERO-FILLED once by the caller, private to one
  * stream; every launch leaves its flag words zero again) and every K a multiple of 64, the call runs 256x256 tiles on the 8-wave kernel with each
  * tile's K range split over a PAIR of workgroups that exchange accumulator halves inside the launch (fixed summation order, no atomics).
- * Without it the 128x128 4-wave kernel runs.  descs[0].force_tile: 0 = choose, 128 = 4-wave kernel, 1256 = 8-wave kernel or error. */
+ * Without it the 128x128 4-wave kernel runs.  descs[0].force_tile: 0 = choose, 128 = 4-wave kernel, 1256 = 8-wave kernel or error.
+ * The first 32-bit word of the workspace is an ERROR word: the pair wait is bounded (~1 s), a block whose partner never became resident raises it
+ * and finishes with an undefined result instead of hanging the device; a caller that reads a non-zero word there must discard that step. */
 int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count);
 /* C[m,n] += sum_s ws[s][m,n] ; bias_grad[m] += sum_s ws_bias[s][m]  (ws layout as written by sam_gemm_bf16; fixed order) */
 int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream);
@@ -128,7 +134,7 @@ int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C,
  * x [M,D] bf16 or fp32 (x_is_f32) -> y bf16, plus per-row mean / rstd (fp32) for the backward. D % 4 == 0, D <= 2048. */
 int sam_layernorm_fwd(const void* x, int x_is_f32, int64_t ldx, const float* gamma, const float* beta, float eps, int M, int D, void* y,
                       int64_t ldy, float* mean, float* rstd, void* stream);
-/* backward of y = LN(x): dx bf16 [M,D]; when dx_dropped != NULL also writes dropout(dx) with the SAME Philox
+/* backward of y = LN(x): dx bf16 [M,D]; when dx_dropped != NULL also writes dropout(dx) with the SAME counter-hash
  * (row, col/8) stream as SAM_EPI_BIAS_DROPOUT_RES used in the forward (the gradient of the dense in front of the
  * residual add); dgamma/dbeta/dbias fp32 [D] (dbias = column sums of the dropped dx; may be NULL); accumulate: += .
  * ws: sam_layernorm_bwd_ws_bytes(D) bytes of scratch. Deterministic two-stage reductions (no atomics). */
@@ -193,7 +199,7 @@ int sam_embedding_bwd_sorted(const void* dy, int64_t ldd, const int64_t* idx_sor
  *   ws: sam_embed_sum_bwd_ws_bytes).  The table gradient is sam_embedding_bwd.
  * sam_gather2_add_fwd: out[b,s,:] = (ind < V ? ans[ind,:] : ocr[b*n_ocr + ind - V,:]) + dropout(emb[b,s,:])  -- _batch_gather over
  *   cat([ans_emb, ocr_emb]) + the embedding sum of PrevPredEmbeddings.forward, sam/sa_m4c.py:921-948, without the [B, V+n_ocr, D] table.
- *   ans bf16 [V, D], ocr bf16 [B*n_ocr, D], inds int64 [B, S] (clamped to [0, V+n_ocr)), emb bf16 [B*S, D] or NULL; Philox dropout on emb.
+ *   ans bf16 [V, D], ocr bf16 [B*n_ocr, D], inds int64 [B, S] (clamped to [0, V+n_ocr)), emb bf16 [B*S, D] or NULL; counter-hash dropout on emb.
  * sam_gather2_add_bwd: d_ans[ind,:] += dy / d_ocr[...] += dy (fp32 atomics into pre-zeroed buffers: indices repeat);
  *   d_emb (bf16, may be NULL) = the same dropout mask applied to dy. */
 int sam_l2norm_pack_bf16(const float* x, int64_t ldx, int M, int D, int normalize, float eps, void* out, int64_t ldo, int col0, int zero_upto,
@@ -221,6 +227,20 @@ int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, in
  * captured in a hipGraph freezes its by-value arguments; this form lets every replay apply the current learning rates / bias corrections. */
 int sam_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
                       float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, void* stream);
+/* Per-step state of a hipGraph-captured training step, advanced ON THE DEVICE by the graph's first node (nothing the host writes is read by
+ * a replay, so the host may queue replays as far ahead as it likes):
+ *   rng_state[1] += offset_stride (fresh dropout masks; rng_state = the array given to sam_set_rng_state, may be NULL);
+ *   t = ++step_counter[0];  dev_sched = [base_lr[s] * lambda(t - 1) for s < nseg, 1 - beta1^t, 1 - beta2^t] for sam_adam_step_dev, with
+ *   lambda = the LambdaLR of sam/task_utils.py:48-54: linear warm-up from warmup_factor to 1 over warmup_iters steps, then
+ *   lr_decay ^ (number of decay_iters <= step).  Arithmetic in double, rounded to fp32 once. */
+typedef struct sam_lr_schedule {
+  double base_lr[8]; int32_t nseg;
+  int64_t warmup_iters; double warmup_factor;
+  int32_t n_decay; int64_t decay_iters[4]; double lr_decay;
+  double beta1, beta2;
+} sam_lr_schedule;
+int sam_step_advance(unsigned long long* rng_state, uint64_t offset_stride, int64_t* step_counter, const sam_lr_schedule* sched, float* dev_sched,
+                     void* stream);
 int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
 
 /* ---- dropout RNG state in device memory (hipGraph capture) ----

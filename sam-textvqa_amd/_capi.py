@@ -66,11 +66,18 @@ SIGNATURES = {
     "sam_pack_masks_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],
     "sam_set_rng_state": [_vp],
+    "sam_step_advance": [_vp, _u64, _vp, C.c_void_p, _vp, _vp],
 }
 NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
 
 _lib = None
+
+
+class LrSchedule(C.Structure):
+    """mirror of `sam_lr_schedule` (include/sam_hip.h)"""
+    _fields_ = [("base_lr", C.c_double * 8), ("nseg", C.c_int32), ("warmup_iters", _i64), ("warmup_factor", C.c_double), ("n_decay", C.c_int32),
+                ("decay_iters", _i64 * 4), ("lr_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double)]
 
 
 class LnFinalizeItem(C.Structure):

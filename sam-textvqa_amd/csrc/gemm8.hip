@@ -507,12 +507,7 @@ constexpr TileCfg kCfg[3] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int pick8(const GemmArgs& a, int tile, hipStream_t st) {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0; hipGetDevice(&dev);
-    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = device_cu_count();
   int best = -1; float best_score = 0.f;
   for (int c = 0; c < 3; ++c) {
     // 1192 / 1256 / 1448: force 192x192 / 256x256 / 192x256; 3192: 192x192 with the deferred epilogue (measured slower)

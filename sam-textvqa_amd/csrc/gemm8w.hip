@@ -237,7 +237,14 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
   if (tid == 0) {
     __hip_atomic_store(w.flags + gtile * 2 + half, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     unsigned* fin = w.flags + gtile * 2 + (1 - half);
-    while (__hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(1);
+    // bounded: HIP does not PROMISE that both blocks of a pair are resident at once (the argument in gemm8w_grouped rests on in-order dispatch).
+    // Should the partner never show up the block gives up after ~1 s, raises the workspace's error word (word 0; the host reads it when it next synchronises: ops.grouped_ws_check)
+    // and finishes with garbage instead of hanging the device.
+    unsigned spins = 0;
+    while (__hip_atomic_load(fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > (1u << 24)) { __hip_atomic_store(w.flags - 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+    }
     __hip_atomic_store(fin, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // consumed: the next launch finds every flag at zero again
   }
   __syncthreads();
@@ -262,7 +269,8 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
 
 namespace samgemm {
 
-int64_t gemm8w_ws_bytes(int tiles) { return (int64_t)tiles * 2 * SLOT_FLOATS * 4 + (int64_t)tiles * 2 * 4 + 256; }
+// [64 words: word 0 = error flag][tiles * 2 pair flags, padded to 64 words][tiles * 2 slots]
+int64_t gemm8w_ws_bytes(int tiles) { return (int64_t)tiles * 2 * SLOT_FLOATS * 4 + (int64_t)(64 + (tiles * 2 + 63) / 64 * 64) * 4 + 256; }
 
 // returns SAM_ERR_UNSUPPORTED when the problem set is not one for this kernel (the caller falls back to the 4-wave grouped kernel)
 int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
@@ -282,12 +290,7 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
     min_kt = d->K / BK < min_kt ? d->K / BK : min_kt;
   }
   w.tile_start[count] = tiles;
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0; hipGetDevice(&dev);
-    hipDeviceProp_t prop; hipGetDeviceProperties(&prop, dev);
-    n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-  }
+  const int n_cu = device_cu_count();
   // the pair exchange spins on the partner, so both blocks of a tile must become resident: one launch round (tiles * 2 <= CUs, one block per
   // CU).  Partners have adjacent item ids (block ids b, b + 8), and workgroups are dispatched in id order: should other work hold some CUs,
   // the resident set is still a prefix of the ids, every pair inside it completes and frees its CUs -- the wait cannot deadlock.
@@ -296,8 +299,8 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   if (w.split == 2) {
     const sam_gemm_desc* d0 = descs;
     if (!d0->ws || d0->ws_bytes < gemm8w_ws_bytes(tiles) || ((uintptr_t)d0->ws % 16) != 0) return SAM_ERR_UNSUPPORTED;
-    w.flags = reinterpret_cast<unsigned*>(d0->ws);                                // [tiles * 2] words, zero between launches (the caller zero-fills once)
-    w.ws = d0->ws + ((tiles * 2 + 63) / 64) * 64;
+    w.flags = reinterpret_cast<unsigned*>(d0->ws) + 64;                           // [tiles * 2] words, zero between launches (the caller zero-fills once);
+    w.ws = d0->ws + 64 + ((tiles * 2 + 63) / 64) * 64;                            // word 0 of the workspace: raised by a block whose partner never arrived
   }
   { static int dbg = -1; if (dbg < 0) { const char* e = getenv("SAM_GEMM8W_DBG"); dbg = e ? atoi(e) : 0; } w.dbg = dbg; }
   constexpr size_t LDS = (size_t)2 * STAGE;

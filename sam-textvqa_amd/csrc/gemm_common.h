@@ -290,6 +290,19 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&
   else gemm_epilogue8_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
 }
 
+// CU count of the CURRENT device (cached per device ordinal: a process that drives several GPUs must not size grids from the first one it queried)
+inline int device_cu_count() {
+  static int cache[64] = {};
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev < 0 || dev >= 64) dev = 0;
+  if (cache[dev] == 0) {
+    hipDeviceProp_t prop;
+    cache[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  return cache[dev];
+}
+
 // 8-wave persistent kernels (gemm8.hip).  tile: 0 = heuristic, 1192 / 1256 / 1448 = force the 192x192 / 256x256 / 192x256 configuration.
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.

@@ -752,6 +752,47 @@ extern "C" int sam_adam_step_dev(float* p, const float* g, float* m, float* v, v
   return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, stream);
 }
 
+// Head node of a captured (hipGraph) training step: everything that changes from replay to replay and used to be a by-value argument lives in
+// device memory and is advanced HERE, on the device, in stream order -- the host never writes it while replays are in flight (a pinned
+// host buffer copied per step raced with the replays the host had queued ahead of the GPU).
+//   rng_state[1] += offset_stride             fresh dropout masks for this replay (rng_state may be NULL)
+//   t = ++step[0]                              optimizer step number, 1-based
+//   dev_sched[s] = base_lr[s] * lambda(t - 1)  LambdaLR of sam/task_utils.py:48-54, evaluated at the pre-increment step like current_lrs()
+//   dev_sched[n] = 1 - beta1^t, dev_sched[n+1] = 1 - beta2^t   (double precision, rounded once)
+struct StepSched { double base_lr[8]; double warmup_factor, lr_decay, beta1, beta2; long long warmup_iters, decay_iters[4]; int nseg, n_decay; };
+__global__ void step_advance_kernel(unsigned long long* rng_state, unsigned long long offset_stride, long long* step, StepSched sc, float* dev_sched) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (rng_state) rng_state[1] += offset_stride;
+  const long long it = step[0], t = it + 1;
+  step[0] = t;
+  double lam;
+  if (it <= sc.warmup_iters) {
+    const double alpha = (double)it / (double)sc.warmup_iters;
+    lam = sc.warmup_factor * (1.0 - alpha) + alpha;
+  } else {
+    int k = 0;
+    for (int q = 0; q < sc.n_decay; ++q) k += sc.decay_iters[q] <= it ? 1 : 0;      // bisect_right
+    lam = pow(sc.lr_decay, (double)k);
+  }
+  for (int s = 0; s < sc.nseg; ++s) dev_sched[s] = (float)(sc.base_lr[s] * lam);
+  dev_sched[sc.nseg] = (float)(1.0 - pow(sc.beta1, (double)t));
+  dev_sched[sc.nseg + 1] = (float)(1.0 - pow(sc.beta2, (double)t));
+}
+extern "C" int sam_step_advance(unsigned long long* rng_state, uint64_t offset_stride, int64_t* step_counter, const sam_lr_schedule* sched, float* dev_sched,
+                                void* stream) {
+  SAM_REQUIRE(step_counter && sched && dev_sched, "sam_step_advance: null pointer");
+  SAM_REQUIRE(sched->nseg >= 1 && sched->nseg <= 8 && sched->n_decay >= 0 && sched->n_decay <= 4 && sched->warmup_iters >= 1,
+              "sam_step_advance: 1..8 segments, at most 4 decay points, warmup_iters >= 1");
+  StepSched sc = {};
+  for (int s = 0; s < sched->nseg; ++s) sc.base_lr[s] = sched->base_lr[s];
+  for (int q = 0; q < sched->n_decay; ++q) sc.decay_iters[q] = sched->decay_iters[q];
+  sc.warmup_factor = sched->warmup_factor; sc.lr_decay = sched->lr_decay; sc.beta1 = sched->beta1; sc.beta2 = sched->beta2;
+  sc.warmup_iters = sched->warmup_iters; sc.nseg = sched->nseg; sc.n_decay = sched->n_decay;
+  step_advance_kernel<<<dim3(1), dim3(64), 0, (hipStream_t)stream>>>(rng_state, (unsigned long long)offset_stride, (long long*)step_counter, sc, dev_sched);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 // out = dropout(a [+ b]) on bf16 [M, D] rows: the element-wise dropout of the object / OCR input encoders (sam/sa_m4c.py:224,263: F.dropout on the
 // sum of the two LayerNorm outputs) and, with b = NULL and dy in place of a, its backward (the mask is regenerated from the same counters).
 // One 16-byte chunk per thread = one (row, col / 8) draw of the hidden-state dropout stream.

@@ -4,7 +4,9 @@
 // Python through PyTorch-ROCm custom ops".  This file is that layer: TORCH_LIBRARY schemas + ROCm implementations that check their tensors
 // (TORCH_CHECK -> RuntimeError), allocate outputs through ATen, enqueue on c10::hip::getCurrentHIPStream() and never synchronise.
 // No arithmetic happens here: every op is one or several calls into include/sam_hip.h.
-//   fine-grained ops   sam_hip::linear, spatial_attn_fwd / _bwd, layernorm_fwd / _bwd        (module-level API, tests, external callers)
+//   fine-grained ops   sam_hip::linear, spatial_attn_fwd / _bwd, layernorm_fwd / _bwd, pack_masks, mask_bits_prefix_lm, mask_bits_from_additive,
+//                      pack_relations (+ _bhnn), ptr_scores (+ _bwd), bce_loss, sumsq, adam_step, step_advance   (SURVEY 8(b)'s op list; the model's
+//                      masks, pointer scores, loss and optimizer go through these)
 //   coarse ops         sam_hip::encoder_layer_fwd / _bwd: one SpatialBertLayer / BertLayer (sam/sa_m4c.py:660-684) = 7 launches forward,
 //                      ~12 backward, enqueued from C++ -- the Python/ctypes route costs ~20 us of host time per launch, 5.7 ms per training
 //                      step against 8 ms of GPU time.
@@ -14,6 +16,7 @@
 #include <torch/library.h>
 
 #include <tuple>
+#include <string>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -203,6 +206,142 @@ void ln_finalize_flush() {
   q.keep.clear();          // (the flush runs on the stream the partials were written on: stream order protects the workspaces)
 }
 
+void ln_finalize_clear() {      // a backward pass that raised: drop what it queued (the partial-sum workspaces may already be gone) and stop deferring
+  LnQueue& q = ln_queue();
+  std::lock_guard<std::mutex> lock(q.mu);
+  q.items.clear();
+  q.keep.clear();
+  q.defer = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- masks (pack_relations)
+int64_t words_per_row(int64_t n) {
+  const int nw = sam_attn_words_per_row((int)n);
+  TORCH_CHECK(nw > 0, "sequence length ", n, " exceeds the fused-attention limit (384 keys)");
+  return nw;
+}
+// question / object / OCR padding masks (int64) -> (key_valid u8 [B, T+No+Nc], question u8 [B,T], ocr u8 [B,Nc]); sa_m4c.py:805-812, :386, :889
+std::tuple<Tensor, Tensor, Tensor> pack_masks(const Tensor& q, const Tensor& o, const Tensor& c) {
+  need(q, at::kLong, "question_mask"); need(o, at::kLong, "pad_obj_mask"); need(c, at::kLong, "pad_ocr_mask");
+  TORCH_CHECK(q.dim() == 2 && o.dim() == 2 && c.dim() == 2 && q.is_contiguous() && o.is_contiguous() && c.is_contiguous(), "pack_masks: contiguous [B, n] masks");
+  const int64_t b = q.size(0), t = q.size(1), no = o.size(1), nc = c.size(1);
+  auto u8 = q.options().dtype(at::kByte);
+  Tensor kv = at::empty({b, t + no + nc}, u8), q8 = at::empty({b, t}, u8), c8 = at::empty({b, nc}, u8);
+  ok(sam_pack_masks_u8((const int64_t*)q.data_ptr(), (int)t, (const int64_t*)o.data_ptr(), (int)no, (const int64_t*)c.data_ptr(), (int)nc, (int)b,
+                       (uint8_t*)kv.data_ptr(), (uint8_t*)q8.data_ptr(), (uint8_t*)c8.data_ptr(), cur_stream()), "sam_pack_masks_u8");
+  return {kv, q8, c8};
+}
+Tensor mask_bits_prefix_lm(const Tensor& key_valid, int64_t n_dec) {                  // sa_m4c.py:805-844
+  need(key_valid, at::kByte, "key_valid");
+  TORCH_CHECK(key_valid.dim() == 2 && key_valid.is_contiguous(), "key_valid: contiguous uint8 [B, n_enc]");
+  const int64_t b = key_valid.size(0), n_enc = key_valid.size(1), n = n_enc + n_dec, nw = words_per_row(n);
+  Tensor out = at::empty({b, 1, n, nw}, key_valid.options().dtype(at::kInt));
+  ok(sam_mask_bits_prefix_lm((const uint8_t*)key_valid.data_ptr(), (int)b, (int)n_enc, (int)n_dec, (int)nw, (uint32_t*)out.data_ptr(), cur_stream()), "sam_mask_bits_prefix_lm");
+  return out;
+}
+Tensor mask_bits_from_additive(const Tensor& mask) {                                  // sa_m4c.py:453-455
+  need(mask, at::kFloat, "attention_mask");
+  TORCH_CHECK(mask.dim() == 4 && mask.size(1) == 1 && mask.size(2) == mask.size(3) && mask.is_contiguous(), "attention_mask must be a contiguous [B,1,N,N] tensor");
+  const int64_t b = mask.size(0), n = mask.size(2), nw = words_per_row(n);
+  Tensor out = at::empty({b, 1, n, nw}, mask.options().dtype(at::kInt));
+  ok(sam_mask_bits_from_additive((const float*)mask.data_ptr(), (int)b, (int)n, (int)nw, (uint32_t*)out.data_ptr(), cur_stream()), "sam_mask_bits_from_additive");
+  return out;
+}
+// the relation tensor of the batch (int8 [B, Noo, Noo, R] multi-hot, dataset layout) AND-ed into the base bits, per head; sa_m4c.py:470-552,568
+Tensor pack_relations(const Tensor& base_bits, const Tensor& adj, int64_t n_txt, int64_t heads, int64_t quadrant_bits) {
+  need(base_bits, at::kInt, "base_bits"); need(adj, at::kChar, "spatial_adj_matrix");
+  TORCH_CHECK(base_bits.dim() == 4 && base_bits.is_contiguous() && adj.dim() == 4 && adj.is_contiguous(), "pack_relations: contiguous base [B,1,N,NW], adj [B,Noo,Noo,R]");
+  const int64_t b = base_bits.size(0), n = base_bits.size(2), nw = base_bits.size(3);
+  Tensor out = at::empty({b, heads, n, nw}, base_bits.options());
+  ok(sam_mask_bits_spatial((const uint32_t*)base_bits.data_ptr(), (const int8_t*)adj.data_ptr(), (int)b, (int)n, (int)nw, (int)n_txt, (int)adj.size(1), (int)adj.size(3),
+                           (int)heads, (unsigned)quadrant_bits, (uint32_t*)out.data_ptr(), cur_stream()), "sam_mask_bits_spatial");
+  return out;
+}
+Tensor pack_relations_bhnn(const Tensor& rel, const optional<Tensor>& base_bits) {       // north-star layout int8 [B,H,N,N]
+  need(rel, at::kChar, "rel");
+  TORCH_CHECK(rel.dim() == 4 && rel.size(2) == rel.size(3) && rel.is_contiguous(), "rel must be a contiguous int8 [B,H,N,N] tensor");
+  const int64_t b = rel.size(0), h = rel.size(1), n = rel.size(2), nw = words_per_row(n);
+  Tensor out = at::empty({b, h, n, nw}, rel.options().dtype(at::kInt));
+  ok(sam_mask_bits_from_int8_bhnn((const int8_t*)rel.data_ptr(), (const uint32_t*)p(base_bits), (int)b, (int)h, (int)n, (int)nw, (uint32_t*)out.data_ptr(), cur_stream()),
+     "sam_mask_bits_from_int8_bhnn");
+  return out;
+}
+
+// ---------------------------------------------------------------------------------------------------------------- pointer net / loss / optimizer
+Tensor ptr_scores_fwd(const Tensor& q, const Tensor& k, const Tensor& ocr_mask, double scale) {      // sa_m4c.py:891-893
+  need(q, at::kBFloat16, "q"); need(k, at::kBFloat16, "k"); need(ocr_mask, at::kByte, "ocr_mask");
+  TORCH_CHECK(q.dim() == 3 && k.dim() == 3 && q.is_contiguous() && k.is_contiguous() && ocr_mask.is_contiguous(), "ptr_scores: contiguous q [B,S,D], k [B,No,D], mask [B,No]");
+  const int64_t b = q.size(0), s = q.size(1), d = q.size(2), no = k.size(1);
+  Tensor out = at::empty({b, s, no}, q.options().dtype(at::kFloat));
+  ok(sam_ptr_scores_fwd(q.data_ptr(), k.data_ptr(), (const uint8_t*)ocr_mask.data_ptr(), (int)b, (int)s, (int)no, (int)d, (float)scale, (float*)out.data_ptr(), out.stride(0),
+                        out.stride(1), cur_stream()), "sam_ptr_scores_fwd");
+  return out;
+}
+std::tuple<Tensor, Tensor> ptr_scores_bwd(const Tensor& ds, const Tensor& q, const Tensor& k, double scale) {
+  need(ds, at::kFloat, "dscores"); need(q, at::kBFloat16, "q"); need(k, at::kBFloat16, "k");
+  TORCH_CHECK(ds.dim() == 3 && ds.stride(2) == 1 && q.is_contiguous() && k.is_contiguous(), "ptr_scores_bwd: dscores [B,S,No] with unit last stride");
+  const int64_t b = q.size(0), s = q.size(1), d = q.size(2), no = k.size(1);
+  Tensor dq = at::empty_like(q), dk = at::empty_like(k);
+  ok(sam_ptr_scores_bwd((const float*)ds.data_ptr(), ds.stride(0), ds.stride(1), q.data_ptr(), k.data_ptr(), (int)b, (int)s, (int)no, (int)d, (float)scale, dq.data_ptr(),
+                        dk.data_ptr(), cur_stream()), "sam_ptr_scores_bwd");
+  return {dq, dk};
+}
+// M4CDecodingBCEWithMaskLoss (task_utils.py:19-30): value + analytic gradient -> (loss f32 [1], d_fixed bf16 [R,V], d_ocr f32 [R,No])
+std::tuple<Tensor, Tensor, Tensor> bce_loss(const Tensor& fixed, const Tensor& ocr, const Tensor& targets, const Tensor& loss_mask, double grad_scale,
+                                            const optional<Tensor>& global_count) {
+  need(fixed, at::kFloat, "fixed_scores"); need(ocr, at::kFloat, "ocr_scores"); need(targets, at::kFloat, "targets"); need(loss_mask, at::kFloat, "loss_mask");
+  TORCH_CHECK(fixed.dim() == 2 && ocr.dim() == 2 && targets.dim() == 2 && fixed.stride(1) == 1 && ocr.stride(1) == 1 && targets.stride(1) == 1 && loss_mask.is_contiguous(),
+              "bce_loss: 2-D score / target blocks with unit last stride");
+  const int64_t r = fixed.size(0), v = fixed.size(1), no = ocr.size(1);
+  Tensor loss = at::empty({1}, fixed.options()), d_fixed = at::empty({r, v}, fixed.options().dtype(at::kBFloat16)), d_ocr = at::empty({r, no}, fixed.options());
+  ok(sam_bce_loss((const float*)fixed.data_ptr(), fixed.stride(0), (const float*)ocr.data_ptr(), ocr.stride(0), (const float*)targets.data_ptr(), targets.stride(0),
+                  (const float*)loss_mask.data_ptr(), (int)r, (int)v, (int)no, (float)grad_scale, (const float*)p(global_count), (float*)loss.data_ptr(), d_fixed.data_ptr(),
+                  d_fixed.stride(0), (float*)d_ocr.data_ptr(), d_ocr.stride(0), cur_stream()), "sam_bce_loss");
+  return {loss, d_fixed, d_ocr};
+}
+Tensor& workspace(const char* tag, int64_t bytes, const Tensor& like) {      // per (tag, device, stream) scratch that only grows
+  static std::mutex mu;
+  static std::map<std::tuple<std::string, int, void*>, Tensor> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  Tensor& ws = cache[{std::string(tag), (int)like.get_device(), cur_stream()}];
+  if (!ws.defined() || ws.numel() * 4 < bytes) ws = at::empty({(bytes + 3) / 4}, like.options().dtype(at::kFloat));
+  return ws;
+}
+void sumsq(const Tensor& g, Tensor out) {                                       // clip_grad_norm_'s norm, train.py:139
+  need(g, at::kFloat, "g"); need(out, at::kFloat, "out");
+  Tensor& ws = workspace("sumsq", sam_sumsq_ws_bytes(), g);
+  ok(sam_sumsq_f32((const float*)g.data_ptr(), g.numel(), (float*)out.data_ptr(), (float*)ws.data_ptr(), cur_stream()), "sam_sumsq_f32");
+}
+// clip + Adam + bf16 shadow refresh over the flat buffers (train.py:139-142, task_utils.py:33-57).  dev_sched given: schedule read from device memory
+// (captured steps, see step_advance); else seg_lr / step by value.
+void adam_step(Tensor p_, const Tensor& g, Tensor m, Tensor v, const optional<Tensor>& p_bf16, at::IntArrayRef seg_end, at::ArrayRef<double> seg_lr, int64_t step,
+               double beta1, double beta2, double eps, const optional<Tensor>& gnorm_sq, double max_norm, const optional<Tensor>& dev_sched) {
+  need(p_, at::kFloat, "p"); need(g, at::kFloat, "g"); need(m, at::kFloat, "exp_avg"); need(v, at::kFloat, "exp_avg_sq");
+  TORCH_CHECK(seg_end.size() >= 1 && seg_end.size() <= 8, "adam_step: 1..8 segments");
+  int64_t ends[8]; float lrs[8] = {};
+  for (size_t s = 0; s < seg_end.size(); ++s) { ends[s] = seg_end[s]; lrs[s] = s < seg_lr.size() ? (float)seg_lr[s] : 0.f; }
+  if (dev_sched.has_value() && dev_sched->defined())
+    ok(sam_adam_step_dev((float*)p_.data_ptr(), (const float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, (int)seg_end.size(),
+                         (float)beta1, (float)beta2, (float)eps, (const float*)dev_sched->data_ptr(), (const float*)p(gnorm_sq), (float)max_norm, cur_stream()), "sam_adam_step_dev");
+  else
+    ok(sam_adam_step((float*)p_.data_ptr(), (const float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, lrs, (int)seg_end.size(),
+                     (float)beta1, (float)beta2, (float)eps, step, (const float*)p(gnorm_sq), (float)max_norm, cur_stream()), "sam_adam_step");
+}
+// head node of a captured training step (include/sam_hip.h: sam_step_advance)
+void step_advance(const optional<Tensor>& rng_state, int64_t offset_stride, Tensor step_counter, at::ArrayRef<double> base_lr, int64_t warmup_iters, double warmup_factor,
+                  at::IntArrayRef decay_iters, double lr_decay, double beta1, double beta2, Tensor dev_sched) {
+  need(step_counter, at::kLong, "step_counter"); need(dev_sched, at::kFloat, "dev_sched");
+  TORCH_CHECK(base_lr.size() >= 1 && base_lr.size() <= 8 && decay_iters.size() <= 4 && (int64_t)dev_sched.numel() >= (int64_t)base_lr.size() + 2, "step_advance: bad schedule sizes");
+  sam_lr_schedule sc = {};
+  sc.nseg = (int32_t)base_lr.size();
+  for (size_t s = 0; s < base_lr.size(); ++s) sc.base_lr[s] = base_lr[s];
+  sc.warmup_iters = warmup_iters; sc.warmup_factor = warmup_factor; sc.n_decay = (int32_t)decay_iters.size();
+  for (size_t q = 0; q < decay_iters.size(); ++q) sc.decay_iters[q] = decay_iters[q];
+  sc.lr_decay = lr_decay; sc.beta1 = beta1; sc.beta2 = beta2;
+  ok(sam_step_advance((unsigned long long*)p(rng_state), (uint64_t)offset_stride, (int64_t*)step_counter.data_ptr(), &sc, (float*)dev_sched.data_ptr(), cur_stream()),
+     "sam_step_advance");
+}
+
 // ---------------------------------------------------------------------------------------------------------------- coarse: one encoder layer
 // params: wqkv bf16 [3D,D], bqkv f32 [3D], wo bf16 [D,D], bo f32, ln1_w, ln1_b, w1 bf16 [I,D], b1 f32, w2 bf16 [D,I], b2 f32, ln2_w, ln2_b
 enum { P_WQKV, P_BQKV, P_WO, P_BO, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B2, P_LN2W, P_LN2B, P_COUNT };
@@ -294,6 +433,20 @@ TORCH_LIBRARY(sam_hip, m) {
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor gamma) -> (Tensor, Tensor, Tensor)");
   m.def("set_ln_defer(bool on) -> ()");
   m.def("ln_finalize_flush() -> ()");
+  m.def("ln_finalize_clear() -> ()");
+  m.def("pack_masks(Tensor question_mask, Tensor obj_mask, Tensor ocr_mask) -> (Tensor, Tensor, Tensor)");
+  m.def("mask_bits_prefix_lm(Tensor key_valid, int n_dec) -> Tensor");
+  m.def("mask_bits_from_additive(Tensor mask) -> Tensor");
+  m.def("pack_relations(Tensor base_bits, Tensor adj, int n_txt, int heads, int quadrant_bits) -> Tensor");
+  m.def("pack_relations_bhnn(Tensor rel, Tensor? base_bits) -> Tensor");
+  m.def("ptr_scores(Tensor q, Tensor k, Tensor ocr_mask, float scale) -> Tensor");
+  m.def("ptr_scores_bwd(Tensor dscores, Tensor q, Tensor k, float scale) -> (Tensor, Tensor)");
+  m.def("bce_loss(Tensor fixed, Tensor ocr, Tensor targets, Tensor loss_mask, float grad_scale, Tensor? global_count) -> (Tensor, Tensor, Tensor)");
+  m.def("sumsq(Tensor g, Tensor(a!) out) -> ()");
+  m.def("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, Tensor(d!)? p_bf16, int[] seg_end, float[] seg_lr, int step, float beta1, float beta2, float eps, "
+        "Tensor? gnorm_sq, float max_norm, Tensor? dev_sched) -> ()");
+  m.def("step_advance(Tensor(a!)? rng_state, int offset_stride, Tensor(b!) step_counter, float[] base_lr, int warmup_iters, float warmup_factor, int[] decay_iters, "
+        "float lr_decay, float beta1, float beta2, Tensor(c!) dev_sched) -> ()");
   m.def("encoder_layer_fwd(Tensor x, Tensor allow, Tensor[] params, int batch, int heads, float scale, float p_attn, float p_hid, int[] seeds, float eps1, "
         "float eps2) -> Tensor[]");
   m.def("encoder_layer_bwd(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
@@ -303,6 +456,7 @@ TORCH_LIBRARY(sam_hip, m) {
 TORCH_LIBRARY_IMPL(sam_hip, CompositeExplicitAutograd, m) {      // no tensor arguments to dispatch on
   m.impl("set_ln_defer", set_ln_defer);
   m.impl("ln_finalize_flush", ln_finalize_flush);
+  m.impl("ln_finalize_clear", ln_finalize_clear);
 }
 
 TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under the CUDA dispatch key)
@@ -313,4 +467,15 @@ TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under
   m.impl("layernorm_bwd", layernorm_bwd_op);
   m.impl("encoder_layer_fwd", encoder_layer_fwd);
   m.impl("encoder_layer_bwd", encoder_layer_bwd);
+  m.impl("pack_masks", pack_masks);
+  m.impl("mask_bits_prefix_lm", mask_bits_prefix_lm);
+  m.impl("mask_bits_from_additive", mask_bits_from_additive);
+  m.impl("pack_relations", pack_relations);
+  m.impl("pack_relations_bhnn", pack_relations_bhnn);
+  m.impl("ptr_scores", ptr_scores_fwd);
+  m.impl("ptr_scores_bwd", ptr_scores_bwd);
+  m.impl("bce_loss", bce_loss);
+  m.impl("sumsq", sumsq);
+  m.impl("adam_step", adam_step);
+  m.impl("step_advance", step_advance);
 }

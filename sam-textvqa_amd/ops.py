@@ -5,8 +5,14 @@ pointers + the current HIP stream to libsam_hip.so and never synchronises."""
 import torch
 
 from . import _capi as capi
+from . import torchops
 
 BF16 = torch.bfloat16
+
+
+def _tops():
+    """torch.ops.sam_hip when the custom-op route is on (default) and bench.py's per-call event profiler is not recording (it brackets ctypes calls)"""
+    return torchops.ns() if (torchops.enabled() and capi.profiler is None) else None
 
 
 def _chk(t, dtype, name):
@@ -35,6 +41,9 @@ def pack_masks(question_mask, obj_mask, ocr_mask):
             raise capi.SamHipError("pack_masks: masks must live on the GPU")
         ms.append(m.contiguous() if m.dtype == torch.int64 else m.ne(0).to(torch.int64).contiguous())
     q, o, c = ms
+    t_ = _tops()
+    if t_ is not None:
+        return t_.pack_masks(q, o, c)
     b, t, no, nc = q.shape[0], q.shape[1], o.shape[1], c.shape[1]
     kv = torch.empty((b, t + no + nc), dtype=torch.uint8, device=q.device)
     q8 = torch.empty((b, t), dtype=torch.uint8, device=q.device)
@@ -46,6 +55,9 @@ def pack_masks(question_mask, obj_mask, ocr_mask):
 def mask_bits_prefix_lm(key_valid, n_dec):
     """key_valid: uint8 [B, n_enc] -> uint32 [B, 1, N, NW] (MMT prefix-LM/causal mask, sa_m4c.py:805-844)."""
     _chk(key_valid, torch.uint8, "key_valid")
+    t_ = _tops()
+    if t_ is not None:
+        return t_.mask_bits_prefix_lm(key_valid, int(n_dec))
     b, n_enc = key_valid.shape
     n = n_enc + n_dec
     nw = words_per_row(n)
@@ -60,6 +72,9 @@ def mask_bits_from_additive(mask):
     b, one, n, n2 = mask.shape
     if one != 1 or n != n2:
         raise capi.SamHipError("attention_mask must be [B,1,N,N], got %s" % (tuple(mask.shape),))
+    t_ = _tops()
+    if t_ is not None:
+        return t_.mask_bits_from_additive(mask)
     nw = words_per_row(n)
     out = torch.empty((b, 1, n, nw), dtype=torch.int32, device=mask.device)
     capi.call("sam_mask_bits_from_additive", capi.ptr(mask), b, n, nw, capi.ptr(out), capi.stream_handle())
@@ -77,6 +92,9 @@ def mask_bits_spatial(base_bits, adj, n_txt, n_heads, quadrants):
         if quad not in (1, 2, 4, 7, 8, 9):
             raise ValueError("illegal attention_mask_quadrants entry %r" % (quad,))  # sa_m4c.py:548-549
         qbits |= 1 << quad
+    t_ = _tops()
+    if t_ is not None:
+        return t_.pack_relations(base_bits, adj, int(n_txt), int(n_heads), qbits)
     out = torch.empty((b, n_heads, n, nw), dtype=torch.int32, device=adj.device)
     capi.call("sam_mask_bits_spatial", capi.ptr(base_bits), capi.ptr(adj), b, n, nw, n_txt, n_oo, r, n_heads, qbits,
               capi.ptr(out), capi.stream_handle())
@@ -226,6 +244,12 @@ class LnFinalizeQueue:
             capi.call("sam_layernorm_bwd_finalize_batch", arr, len(its), d, capi.stream_handle())
         cls.items = []
 
+    @classmethod
+    def clear(cls):
+        """drop queued finalizes without running them (a backward pass that raised: their workspaces may be gone)"""
+        cls.items = []
+        cls.defer = False
+
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dgamma, dbeta, dbias=None, want_dropped=False, p_drop=0.0, seed=0, offset=0, accumulate=True, may_defer=False):
     """-> (dx bf16, dx_dropped bf16 or None); dgamma/dbeta/dbias (fp32 [D]) are accumulated in place (overwritten with accumulate=False).
@@ -329,6 +353,9 @@ def bce_loss(fixed, ocr, targets, loss_mask, grad_scale=1.0, global_count=None):
     global_count (device f32 scalar): the all-reduced number of unmasked steps of the global batch, used as the normaliser instead of this rank's"""
     r, v = fixed.shape
     no = ocr.shape[1]
+    t_ = _tops()
+    if t_ is not None and loss_mask.is_contiguous():
+        return t_.bce_loss(fixed, ocr, targets, loss_mask, float(grad_scale), global_count)
     loss = torch.empty(1, dtype=torch.float32, device=fixed.device)
     d_fixed = torch.empty((r, v), dtype=BF16, device=fixed.device)
     d_ocr = torch.empty((r, no), dtype=torch.float32, device=fixed.device)
@@ -341,6 +368,9 @@ def ptr_scores_fwd(q, k, ocr_mask_u8, scale):
     """q bf16 [B,S,D], k bf16 [B,No,D], mask u8 [B,No] -> f32 [B,S,No]"""
     b, s, d = q.shape
     no = k.shape[1]
+    t_ = _tops()
+    if t_ is not None:
+        return t_.ptr_scores(q, k, ocr_mask_u8, float(scale))
     out = torch.empty((b, s, no), dtype=torch.float32, device=q.device)
     capi.call("sam_ptr_scores_fwd", capi.ptr(q), capi.ptr(k), capi.ptr(ocr_mask_u8), b, s, no, d, float(scale), capi.ptr(out), out.stride(0), out.stride(1),
               capi.stream_handle())
@@ -350,6 +380,9 @@ def ptr_scores_fwd(q, k, ocr_mask_u8, scale):
 def ptr_scores_bwd(dscores, q, k, scale):
     b, s, d = q.shape
     no = k.shape[1]
+    t_ = _tops()
+    if t_ is not None:
+        return t_.ptr_scores_bwd(dscores, q, k, float(scale))
     dq, dk = torch.empty_like(q), torch.empty_like(k)
     capi.call("sam_ptr_scores_bwd", capi.ptr(dscores), dscores.stride(0), dscores.stride(1), capi.ptr(q), capi.ptr(k), b, s, no, d, float(scale),
               capi.ptr(dq), capi.ptr(dk), capi.stream_handle())
@@ -357,12 +390,21 @@ def ptr_scores_bwd(dscores, q, k, scale):
 
 
 def sumsq(g, out):
+    t_ = _tops()
+    if t_ is not None:
+        t_.sumsq(g, out)
+        return out
     ws = _workspace(capi.call("sam_sumsq_ws_bytes"), g.device, "sumsq")
     capi.call("sam_sumsq_f32", capi.ptr(g), g.numel(), capi.ptr(out), capi.ptr(ws), capi.stream_handle())
     return out
 
 
 def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
+    t_ = _tops()
+    if t_ is not None:
+        t_.adam_step(p, g, m, v, p_bf16, [int(e) for e in seg_end], [float(l) for l in seg_lr], int(step), float(betas[0]), float(betas[1]), float(eps), gnorm_sq,
+                     float(max_norm), None)
+        return
     import ctypes as C
     n = len(seg_end)
     ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
@@ -373,11 +415,37 @@ def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm
 
 def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
     """adam_step with the schedule [lr per segment, 1 - beta1^t, 1 - beta2^t] read from the device tensor `dev_sched` (graph-captured steps)"""
+    t_ = _tops()
+    if t_ is not None:
+        t_.adam_step(p, g, m, v, p_bf16, [int(e) for e in seg_end], [], 0, float(betas[0]), float(betas[1]), float(eps), gnorm_sq, float(max_norm), dev_sched)
+        return
     import ctypes as C
     n = len(seg_end)
     ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
     capi.call("sam_adam_step_dev", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, n, float(betas[0]), float(betas[1]),
               float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
+
+
+def step_advance(rng_state, offset_stride, step_counter, base_lrs, dev_sched, betas=(0.9, 0.999), warmup_iters=1000, warmup_factor=0.2,
+                 lr_decay_iters=(14000, 19000), lr_decay=0.1):
+    """head node of a captured training step (sam_step_advance): rng_state[1] += offset_stride; t = ++step_counter[0];
+    dev_sched = [base_lr * lambda(t - 1) per segment, 1 - beta1^t, 1 - beta2^t], all in device memory"""
+    t_ = _tops()
+    if t_ is not None:
+        t_.step_advance(rng_state, int(offset_stride), step_counter, [float(l) for l in base_lrs], int(warmup_iters), float(warmup_factor),
+                        [int(i) for i in lr_decay_iters], float(lr_decay), float(betas[0]), float(betas[1]), dev_sched)
+        return
+    import ctypes as C
+    sc = capi.LrSchedule()
+    sc.nseg = len(base_lrs)
+    for i, l in enumerate(base_lrs):
+        sc.base_lr[i] = float(l)
+    sc.warmup_iters, sc.warmup_factor, sc.n_decay, sc.lr_decay = int(warmup_iters), float(warmup_factor), len(lr_decay_iters), float(lr_decay)
+    for i, it in enumerate(lr_decay_iters):
+        sc.decay_iters[i] = int(it)
+    sc.beta1, sc.beta2 = float(betas[0]), float(betas[1])
+    capi.call("sam_step_advance", capi.ptr(rng_state), int(offset_stride), capi.ptr(step_counter), C.cast(C.pointer(sc), C.c_void_p), capi.ptr(dev_sched),
+              capi.stream_handle())
 
 
 def set_rng_state(state):
@@ -408,6 +476,9 @@ def mask_bits_from_int8_bhnn(rel, base_bits=None):
     """rel int8 [B,H,N,N] (non-zero = visible), optional base bits [B,1,N,NW] -> uint32 [B,H,N,NW]"""
     _chk(rel, torch.int8, "rel")
     b, h, n, n2 = rel.shape
+    t_ = _tops()
+    if t_ is not None:
+        return t_.pack_relations_bhnn(rel, base_bits)
     nw = words_per_row(n)
     out = torch.empty((b, h, n, nw), dtype=torch.int32, device=rel.device)
     capi.call("sam_mask_bits_from_int8_bhnn", capi.ptr(rel), capi.ptr(base_bits), b, h, n, nw, capi.ptr(out), capi.stream_handle())
@@ -435,6 +506,22 @@ def _grouped_ws(device, nbytes):
         buf = torch.zeros(((nbytes + 3) // 4,), dtype=torch.float32, device=device)
         _GROUPED_WS[key] = buf
     return buf
+
+
+def grouped_ws_check():
+    """raise if any pair exchange of sam_gemm_bf16_grouped gave up waiting for its partner block (error word of the workspace; synchronises)"""
+    for key, buf in _GROUPED_WS.items():
+        if int(buf[:1].view(torch.int32).item()) != 0:
+            buf[:1].zero_()
+            raise capi.SamHipError("sam_gemm_bf16_grouped: a workgroup pair never became co-resident (device %s); the step's weight gradients are invalid" % (key[0],))
+
+
+def reset_workspaces():
+    """forget every cached scratch buffer (after a failed step: a grouped-wgrad workspace may hold stale pair flags, an LN scratch stale partials);
+    the next call allocates fresh, zero-filled ones"""
+    _GROUPED_WS.clear()
+    _WS.clear()
+    LnFinalizeQueue.clear()
 
 
 def wgrad_grouped(jobs, force_tile=0, accumulate=True):

@@ -37,7 +37,7 @@ class GradReducer:
         # (text_bert_init_from_bert_base) the table sits in the middle of the buffer, in front of the rest of TextBert.
         self.sparse_lo, self.sparse_hi = (0, int(dense_lo)) if sparse_range is None else (int(sparse_range[0]), int(sparse_range[1]))
         self.dense_lo = self.sparse_hi if self.sparse_lo == 0 else 0
-        self._checked_rows = False
+        self._checked_rows = -1
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         # SAM_FORCE_DIST=1: run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
@@ -188,12 +188,22 @@ class GradReducer:
         the data-parallel exchange of a row-sparse gradient living in [0, dense_lo)."""
         if self.world_size > 1 or self.force:
             w = self.world_size
-            if not self._checked_rows:                  # all_gather_into_tensor needs the same row count on every rank: check it once, loudly
+            if self._checked_rows < 0:                  # all_gather_into_tensor needs the same row count on every rank: verified, loudly, on
+                                                        # the first call (every rank makes it: no rank can skip the collective)
                 cnt = torch.tensor([ids.numel(), -ids.numel()], dtype=torch.int64, device=ids.device)
                 dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
                 if int(cnt[0]) != -int(cnt[1]):
                     raise RuntimeError("GradReducer.sparse_rows: ranks hold different numbers of rows (%d..%d); pad the last batch" % (-int(cnt[1]), int(cnt[0])))
-                self._checked_rows = True
+                self._checked_rows = ids.numel()
+            elif ids.numel() < self._checked_rows:
+                # a SHORTER list later on (uneven last batch on this rank): padded up to the verified count with out-of-range indices, which the
+                # scatter skips -- every rank still gathers equal-sized pieces and no extra collective (that only some ranks would enter) is needed
+                pad = self._checked_rows - ids.numel()
+                ids = torch.cat([ids.reshape(-1), torch.full((pad,), -1, dtype=ids.dtype, device=ids.device)])
+                rows = torch.cat([rows, rows.new_zeros((pad, rows.shape[1]))])
+            elif ids.numel() > self._checked_rows:
+                raise RuntimeError("GradReducer.sparse_rows: %d rows on this rank, %d were verified equal across ranks on the first step; "
+                                   "batches may shrink (they are padded) but not grow" % (ids.numel(), self._checked_rows))
             ids, rows = ids.contiguous(), rows.contiguous()
             ids_all = torch.empty((w * ids.numel(),), dtype=ids.dtype, device=ids.device)
             rows_all = torch.empty((w * rows.shape[0], rows.shape[1]), dtype=rows.dtype, device=rows.device)

@@ -172,6 +172,12 @@ class Trainer:
         if torchops.enabled():
             torchops.ns().ln_finalize_flush()
 
+    def _ln_clear(self):
+        from . import torchops
+        ops.LnFinalizeQueue.clear()
+        if torchops.enabled():
+            torchops.ns().ln_finalize_clear()
+
     def _sparse_table_range(self):
         """the word-embedding table's [lo, hi) in flat storage when it can be exchanged row-sparsely (parallel.GradReducer.sparse_rows):
         it must start its optimizer group's segment or the buffer, so that the dense ranges around it stay whole; else None"""
@@ -225,6 +231,12 @@ class Trainer:
             self._set_ln_defer(True)
         try:
             loss.backward()
+        except BaseException:
+            # whatever the LayerNorm backwards queued points into workspaces of a backward pass that no longer exists (under capture: into the
+            # graph's private pool): drop it, or the next step's flush would reduce stale partial sums into dgamma / dbeta / dbias
+            self._ln_clear()
+            parallel.active_reducer = None
+            raise
         finally:
             if defer_ln:
                 self._set_ln_defer(False)
@@ -290,6 +302,8 @@ class Trainer:
                 import logging
                 logging.getLogger(__name__).warning("hipGraph capture of the training step failed (%s: %s); continuing eagerly", type(e).__name__, e)
                 ops.set_rng_state(None)
+                self._ln_clear()                                 # nothing a half-recorded backward queued may survive into the eager step
+                ops.reset_workspaces()
                 self.use_graph, self._graph = False, None
                 return self._eager_step(batch_dict)
         stale = [(dst, v) for (k, kk, v), dst in zip(items, self._static_in) if v.data_ptr() != dst.data_ptr()]
@@ -299,17 +313,17 @@ class Trainer:
             except (RuntimeError, AttributeError):
                 for d, v in stale:
                     d.copy_(v, non_blocking=True)
-        lrs = self.current_lrs()
-        t = self.global_step + 1
-        host = self._sched_host
-        for i, lr in enumerate(lrs):
-            host[i] = lr
-        host[len(lrs)] = 1.0 - self.betas[0] ** t
-        host[len(lrs) + 1] = 1.0 - self.betas[1] ** t
-        self._sched_dev.copy_(host, non_blocking=True)
+        # The step number, the learning rates and Adam's bias corrections live in device memory and are advanced by the graph's first node
+        # (ops.step_advance): nothing a replay reads is written by the host, so the host may queue replays arbitrarily far ahead of the GPU.
+        # Only when the host's own count was changed behind the graph's back (checkpoint resume, an eager step of another shape in between) is
+        # the device counter re-seeded -- by a fill whose value travels BY VALUE in stream order.
+        if self.global_step != self._dev_step_mirror:
+            self._step_dev.fill_(self.global_step)
+            self._dev_step_mirror = self.global_step
         self._graph.replay()
         self.global_step += 1
-        return self._static_loss
+        self._dev_step_mirror += 1
+        return self._static_loss.clone()                         # (the static tensor is overwritten by the next replay: callers may keep what they get)
 
     def input_buffers(self):
         """the captured step's own input tensors as a batch_dict (None before the capture).  A data pipeline that writes the next batch straight into
@@ -333,8 +347,9 @@ class Trainer:
             else:
                 static_bd.setdefault(k, {})[kk] = t
         n = len(self.group_lr)
-        self._sched_host = torch.zeros(n + 2, dtype=torch.float32).pin_memory()
         self._sched_dev = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+        self._step_dev = torch.full((1,), self.global_step, dtype=torch.int64, device=dev)
+        self._dev_step_mirror = self.global_step
         self._rng_state = torch.tensor([dropout_clock.seed & 0x7FFFFFFFFFFFFFFF, dropout_clock.offset + self.GRAPH_OFFSET_STRIDE], dtype=torch.int64, device=dev)
         saved_offset, dropout_clock.offset = dropout_clock.offset, 0          # by-value offsets inside the graph: 1, 2, 3, ... per site
         g = torch.cuda.CUDAGraph()
@@ -342,7 +357,8 @@ class Trainer:
         ops.set_rng_state(self._rng_state)
         try:
             with torch.cuda.graph(g, stream=self._cap_stream):
-                self._rng_state[1:2].add_(self.GRAPH_OFFSET_STRIDE)           # first node: fresh masks for this replay
+                # first node: fresh dropout masks, the step counter, this step's learning rates and bias corrections -- all on the device
+                ops.step_advance(self._rng_state, self.GRAPH_OFFSET_STRIDE, self._step_dev, self.group_lr, self._sched_dev, betas=self.betas, **self.schedule)
                 bd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in static_bd.items()}
                 loss = self._eager_step(bd, sched_dev=self._sched_dev)
                 self._static_loss = loss

@@ -98,7 +98,7 @@ def _sparse_worker(rank, world, port, q):
     grad = torch.zeros(rows_tab * d + dense)
     grad[rows_tab * d:] = (rank + 1.0) / world                       # dense part: pre-scaled per-rank gradients
     def cpu_scatter(table, ids, rows, padding_idx):          # the package only has the HIP scatter; the exchange logic is what is tested here
-        keep = ids != padding_idx
+        keep = (ids != padding_idx) & (ids >= 0) & (ids < table.shape[0])     # (sam_embedding_bwd_sorted skips out-of-range rows the same way)
         table.index_add_(0, ids[keep], rows[keep].to(table.dtype))
     red = GradReducer(grad, bucket_bytes=4 * 128, dense_lo=rows_tab * d, scatter_fn=cpu_scatter)
     assert red.buckets[-1][0] == rows_tab * d and all(lo >= rows_tab * d for lo, _ in red.buckets)   # the table is in no dense bucket
@@ -119,7 +119,26 @@ def _sparse_worker(rank, world, port, q):
         v = torch.randn(12, d, generator=gr).to(torch.bfloat16).float()
         exp.index_add_(0, i[3:], v[3:])
     ok = torch.allclose(table, exp, atol=1e-6) and bool((table[0] == 0).all()) and torch.allclose(grad[rows_tab * d:], torch.full((dense,), sum(range(1, world + 1)) / world))
-    q.put((rank, ok))
+    # second step, uneven last batch: rank 1 holds fewer rows than were verified on the first call; it pads (no extra collective that rank 0 would
+    # not enter) and both ranks still end with everyone's rows
+    table.zero_()
+    n2 = 12 if rank == 0 else 5
+    ids2 = torch.arange(1, n2 + 1) + 10 * rank
+    rows2 = torch.full((n2, d), float(rank + 1)).to(torch.bfloat16)
+    red.begin_step()
+    red.sparse_rows(table, ids2, rows2, padding_idx=0)
+    red.finish()
+    exp2 = torch.zeros(rows_tab, d)
+    exp2.index_add_(0, torch.arange(1, 13), torch.full((12, d), 1.0))
+    exp2.index_add_(0, torch.arange(1, 6) + 10, torch.full((5, d), 2.0))
+    ok = ok and torch.equal(table, exp2)
+    grew = False
+    if rank == 0:                                              # a batch that GROWS is refused locally, before any collective
+        try:
+            red.sparse_rows(table, torch.arange(13), torch.zeros(13, d, dtype=torch.bfloat16), padding_idx=0)
+        except RuntimeError:
+            grew = True
+    q.put((rank, ok and (grew or rank != 0)))
     dist.barrier()
     dist.destroy_process_group()
 

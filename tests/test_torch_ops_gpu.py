@@ -170,3 +170,99 @@ def test_training_step_captured_as_a_hipgraph():
     assert tr._graph is not None and a != b and abs(a - b) < 0.2 * abs(a), (a, b)
     ls = [tr.step(clone_batch(batch)).item() for _ in range(30)]
     assert ls[-1] < 0.8 * ls[0] and not torch.equal(before, tr.flat.flat)
+
+
+def test_survey_8b_ops_equal_the_cabi_route():
+    """masks / pointer scores / loss / optimizer registered under torch.ops.sam_hip (SURVEY 8(b)'s op list): each is the same C entry point
+    as the ctypes route underneath, so the results are bit-identical"""
+    import os
+    from sam_textvqa_amd import _capi as capi, ops, torchops
+    ns = torchops.ns()
+    g = torch.Generator().manual_seed(11)
+    B, T, No, Nc, S, V, D = 3, 20, 100, 50, 12, 500, 768
+
+    def both(fn):
+        os.environ["SAM_COARSE_OPS"] = "0"          # ops.* -> ctypes
+        try:
+            a = fn()
+        finally:
+            os.environ.pop("SAM_COARSE_OPS", None)
+        return a, fn()                               # ops.* -> torch.ops
+
+    qm = (torch.rand(B, T, generator=g) > 0.3).long().cuda()
+    om = (torch.rand(B, No, generator=g) > 0.1).long().cuda()
+    cm = (torch.rand(B, Nc, generator=g) > 0.5).long().cuda()
+    (kv1, q1, c1), (kv2, q2, c2) = both(lambda: ops.pack_masks(qm, om, cm))
+    assert torch.equal(kv1, kv2) and torch.equal(q1, q2) and torch.equal(c1, c2)
+    base1, base2 = both(lambda: ops.mask_bits_prefix_lm(kv1, S))
+    assert torch.equal(base1, base2) and torch.equal(base1, ns.mask_bits_prefix_lm(kv1, S))
+    adj = (torch.rand(B, No + Nc, No + Nc, 12, generator=g) > 0.7).to(torch.int8).cuda()
+    s1, s2 = both(lambda: ops.mask_bits_spatial(base1, adj, T, 12, [1, 2]))
+    assert torch.equal(s1, s2) and torch.equal(s1, ns.pack_relations(base1, adj, T, 12, (1 << 1) | (1 << 2)))
+    add = torch.where(torch.rand(B, 1, 182, 182, generator=g) > 0.4, 0.0, -10000.0).cuda()
+    a1, a2 = both(lambda: ops.mask_bits_from_additive(add))
+    assert torch.equal(a1, a2)
+    rel = (torch.rand(B, 12, 182, 182, generator=g) > 0.5).to(torch.int8).cuda()
+    r1, r2 = both(lambda: ops.mask_bits_from_int8_bhnn(rel, base1))
+    assert torch.equal(r1, r2)
+    # pointer scores fwd / bwd
+    q, k = rnd((B, S, D), 12).cuda(), rnd((B, Nc, D), 13).cuda()
+    p1, p2 = both(lambda: ops.ptr_scores_fwd(q, k, c1, 1.0 / math.sqrt(D)))
+    assert torch.equal(p1, p2)
+    ds = torch.randn(B, S, Nc, generator=g).cuda()
+    (dq1, dk1), (dq2, dk2) = both(lambda: ops.ptr_scores_bwd(ds, q, k, 1.0 / math.sqrt(D)))
+    assert torch.equal(dq1, dq2) and torch.equal(dk1, dk2)
+    # masked BCE
+    fixed, ocr = torch.randn(B * S, V, generator=g).cuda(), torch.randn(B * S, Nc, generator=g).cuda()
+    tg = (torch.rand(B * S, V + Nc, generator=g) > 0.98).float().cuda()
+    lm = (torch.rand(B * S, generator=g) > 0.4).float().cuda()
+    l1, l2 = both(lambda: ops.bce_loss(fixed, ocr, tg, lm, 1.0, None))
+    for x, y in zip(l1, l2):
+        assert torch.equal(x, y)
+    # sumsq + Adam (host schedule and device schedule)
+    n = 4096 * 5
+    def adam(dev):
+        p = torch.linspace(-1, 1, n).cuda(); gr = torch.sin(torch.arange(n).float()).cuda(); m = torch.zeros(n).cuda(); v = torch.zeros(n).cuda()
+        sh = torch.empty(n, dtype=torch.bfloat16).cuda(); nsq = torch.zeros(1).cuda()
+        ops.sumsq(gr, nsq)
+        if dev:
+            ops.adam_step_dev(p, gr, m, v, sh, [4096, n], torch.tensor([1e-3, 1e-4, 0.1, 0.001]).cuda(), gnorm_sq=nsq, max_norm=0.25)
+        else:
+            ops.adam_step(p, gr, m, v, sh, [4096, n], [1e-3, 1e-4], 1, gnorm_sq=nsq, max_norm=0.25)
+        return p, m, v, sh, nsq
+    for dev in (False, True):
+        r1, r2 = both(lambda: adam(dev))
+        for x, y in zip(r1, r2):
+            assert torch.equal(x, y)
+    with pytest.raises(RuntimeError):
+        ns.ptr_scores(q.cpu(), k, c1, 1.0)
+    with pytest.raises(RuntimeError):
+        ns.mask_bits_prefix_lm(kv1.long(), S)
+
+
+def test_step_advance_matches_the_host_schedule():
+    """sam_step_advance (the head node of a captured step): step counter, LambdaLR factor and Adam bias corrections on the device equal the
+    host's lr_lambda / 1 - beta^t at every regime of the schedule, through both routes; the RNG offset base advances by the stride"""
+    import os
+    from sam_textvqa_amd import ops
+    from sam_textvqa_amd.trainer import lr_lambda
+    base = [1e-4, 1e-5, 1e-4]
+    for route in ("0", "1"):
+        os.environ["SAM_COARSE_OPS"] = route
+        try:
+            for it in (0, 1, 2, 499, 999, 1000, 1001, 13999, 14000, 14001, 18999, 19000, 25000):
+                step = torch.tensor([it], dtype=torch.int64).cuda()
+                rng = torch.tensor([7, 100], dtype=torch.int64).cuda()
+                sched = torch.zeros(5).cuda()
+                ops.step_advance(rng, 1 << 20, step, base, sched)
+                t = it + 1
+                want = [l * lr_lambda(it) for l in base] + [1.0 - 0.9 ** t, 1.0 - 0.999 ** t]
+                got = sched.cpu().double().tolist()
+                assert int(step.item()) == t and rng.tolist() == [7, 100 + (1 << 20)]
+                for w_, g_ in zip(want, got):
+                    assert abs(w_ - g_) <= 1.2e-7 * abs(w_), (it, want, got)
+            step = torch.tensor([5], dtype=torch.int64).cuda(); sched = torch.zeros(3).cuda()
+            ops.step_advance(None, 0, step, [1.0], sched, warmup_iters=10, warmup_factor=0.5, lr_decay_iters=(20,), lr_decay=0.5)
+            assert abs(sched[0].item() - (0.5 * 0.5 + 0.5)) < 1e-6
+        finally:
+            os.environ.pop("SAM_COARSE_OPS", None)
