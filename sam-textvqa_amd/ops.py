@@ -10,9 +10,32 @@ from . import torchops
 BF16 = torch.bfloat16
 
 
+class _TorchOpsProxy:
+    """torch.ops.sam_hip with the package's error type: TORCH_CHECK failures (plain RuntimeError) surface as SamHipError, like the ctypes route's"""
+    _cache = {}
+
+    def __getattr__(self, name):
+        fn = self._cache.get(name)
+        if fn is None:
+            op = getattr(torchops.ns(), name)
+
+            def fn(*a, _op=op, **kw):
+                try:
+                    return _op(*a, **kw)
+                except capi.SamHipError:
+                    raise
+                except RuntimeError as e:
+                    raise capi.SamHipError(str(e).split("\n")[0]) from None
+            self._cache[name] = fn
+        return fn
+
+
+_PROXY = _TorchOpsProxy()
+
+
 def _tops():
     """torch.ops.sam_hip when the custom-op route is on (default) and bench.py's per-call event profiler is not recording (it brackets ctypes calls)"""
-    return torchops.ns() if (torchops.enabled() and capi.profiler is None) else None
+    return _PROXY if (torchops.enabled() and capi.profiler is None) else None
 
 
 def _chk(t, dtype, name):

@@ -333,7 +333,68 @@ def main():
         with torch.no_grad():
             arrays["greedy_scores"] = np_(model(bd2)["textvqa_scores"])
             arrays["greedy_prev_inds"] = np_(bd2["train_prev_inds"])
+        # ---- beam search (sam/beam_search.py driven by sa_m4c.py:304-314), the reference's own BeamSearch class.  Two runs: the model's real EOS
+        # index, and an EOS index chosen among the tokens the first run actually emitted so that beams COMPLETE early (the completed-beam
+        # branch, beam_search.py:89-93,140-158, is otherwise never taken by a random-weight model).
+        for tag, beam, eos in beam_cases(model, name, d, case, bd):
+            registry.EOS_IDX = eos
+            model.set_beam_size(beam)
+            bd3 = sam4c_batch(name, d, case, bd["spatial_adj_matrices"][str(case["ctx"])])
+            bd3["train_prev_inds"] = torch.zeros_like(bd3["train_prev_inds"]); bd3["train_prev_inds"][:, 0] = registry.BOS_IDX
+            bd3["question_id"] = torch.arange(d["B"]) + 100
+            trace = []
+            orig_decode = model.bsdecoder.decode
+
+            def traced(batch_dict, t, _orig=orig_decode, _trace=trace):
+                sc = batch_dict["scores"][:, t, :].clone()
+                out = _orig(batch_dict, t)
+                _trace.append((sc, out[1]["train_prev_inds"].clone(), out[1]["topkscores"].clone()))
+                return out
+            model.bsdecoder.decode = traced
+            with torch.no_grad(), legacy_integer_division():
+                res = model(bd3, use_beam_search=True)
+            arrays["beam.%s.cfg" % tag] = np.array([beam, eos, len(trace)])
+            arrays["beam.%s.complete_seqs" % tag] = np_(res["complete_seqs"])
+            arrays["beam.%s.topkscores" % tag] = np_(res["topkscores"])
+            arrays["beam.%s.question_id" % tag] = np_(res["question_id"])
+            arrays["beam.%s.final_scores" % tag] = np_(res["textvqa_scores"])
+            for t, (sc, pi, tk) in enumerate(trace):
+                arrays["beam.%s.step%d.scores" % (tag, t)] = np_(sc)
+                arrays["beam.%s.step%d.prev_inds" % (tag, t)] = np_(pi)
+                arrays["beam.%s.step%d.topkscores" % (tag, t)] = np_(tk)
+        registry.EOS_IDX = 2
         save(name, **arrays)
+
+
+class legacy_integer_division:
+    """`indices / vocab_size` in sam/beam_search.py:113 is integer division: the reference targets torch <= 1.4, where `/` on integer tensors
+    floors (true division for them arrived in torch 1.5/1.6).  For the span of the reference's beam search the old operator is restored for
+    INTEGER tensor / INTEGER operands only; everything else goes to the current implementation."""
+
+    def __enter__(self):
+        self._orig = torch.Tensor.__truediv__
+        orig = self._orig
+
+        def div(a, b):
+            b_int = isinstance(b, int) or (torch.is_tensor(b) and not b.is_floating_point() and not b.is_complex())
+            if torch.is_tensor(a) and not a.is_floating_point() and not a.is_complex() and a.dtype != torch.bool and b_int:
+                return torch.div(a, b, rounding_mode="floor")
+            return orig(a, b)
+        torch.Tensor.__truediv__ = div
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.__truediv__ = self._orig
+
+
+def beam_cases(model, name, d, case, bd):
+    """(tag, beam size, EOS index): `early` takes as EOS the token the greedy decoder emits for sample 0 at step 2, so that beams complete
+    early and keep re-emitting EOS"""
+    bd2 = sam4c_batch(name, d, case, bd["spatial_adj_matrices"][str(case["ctx"])])
+    with torch.no_grad():
+        model(bd2)
+    tok = int(bd2["train_prev_inds"][0, 2])
+    return [("k3", 3, 2), ("early", 4, tok)]
 
 
 def mmt_batch(name, d, ctx, adj):

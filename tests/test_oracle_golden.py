@@ -144,6 +144,36 @@ def test_sam4c_train_and_greedy():
     np.testing.assert_array_equal(bd2["train_prev_inds"].numpy(), g["greedy_prev_inds"])
 
 
+@pytest.mark.parametrize("tag", ["k3", "early"])
+def test_beam_search_against_the_reference_beam_search(tag):
+    """oracle/beam_search.py == the reference's BeamSearch class driven by SAM4C._forward_beam_search (sam/beam_search.py:6-181,
+    sa_m4c.py:304-314): every step's scores, surviving sequences and cumulative scores, and the final results"""
+    from oracle import beam_search as BS
+    name = "sam4c_small_c3"
+    g = OC.load(name)
+    d = C.SAM4C_CASES[name]["dims"]
+    mcfg, tcfg = OC.sam4c_configs(name)
+    model = O.SAM4C(mcfg, tcfg, num_answers=d["V"], bos_idx=1).eval()
+    C.fill_state_dict(model, d["ws"], prefix=name + ".")
+    beam, eos, nsteps = (int(v) for v in g["beam.%s.cfg" % tag])
+    bd = OC.sam4c_batch(name, torch.from_numpy(g["adj"]))
+    bd["train_prev_inds"] = torch.zeros_like(bd["train_prev_inds"]); bd["train_prev_inds"][:, 0] = 1
+    bd["question_id"] = torch.arange(d["B"]) + 100
+    with torch.no_grad():
+        res, _, trace = BS.forward_beam_search(model, bd, beam, eos)
+    assert len(trace) == nsteps
+    for t, (sc, pi, tk) in enumerate(trace):
+        close(sc, g["beam.%s.step%d.scores" % (tag, t)], 5e-5)
+        np.testing.assert_array_equal(pi.numpy(), g["beam.%s.step%d.prev_inds" % (tag, t)])
+        close(tk.float(), g["beam.%s.step%d.topkscores" % (tag, t)], 5e-5)
+    np.testing.assert_array_equal(res["complete_seqs"].numpy(), g["beam.%s.complete_seqs" % tag])
+    np.testing.assert_array_equal(res["question_id"].numpy(), g["beam.%s.question_id" % tag])
+    close(res["topkscores"], g["beam.%s.topkscores" % tag], 5e-5)
+    close(res["textvqa_scores"], g["beam.%s.final_scores" % tag], 5e-5)
+    if tag == "early":          # the completed-beam branch was really taken: some beam carries EOS before the last step
+        assert (g["beam.early.step0.prev_inds"][:, 1] == eos).any()
+
+
 def test_lr_schedule_and_loss_normaliser():
     # task_utils.py:48-54: warm-up 0.2 -> 1 over 1000 iters, x0.1 at 14k and 19k
     assert O.lr_lambda(0) == pytest.approx(0.2) and O.lr_lambda(500) == pytest.approx(0.6) and O.lr_lambda(1000) == 1.0

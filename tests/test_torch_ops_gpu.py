@@ -217,8 +217,8 @@ def test_survey_8b_ops_equal_the_cabi_route():
     tg = (torch.rand(B * S, V + Nc, generator=g) > 0.98).float().cuda()
     lm = (torch.rand(B * S, generator=g) > 0.4).float().cuda()
     l1, l2 = both(lambda: ops.bce_loss(fixed, ocr, tg, lm, 1.0, None))
-    for x, y in zip(l1, l2):
-        assert torch.equal(x, y)
+    assert torch.allclose(l1[0], l2[0], rtol=1e-6)           # (the loss scalar is summed with atomics: the order of the additions is not fixed)
+    assert torch.equal(l1[1], l2[1]) and torch.equal(l1[2], l2[2])
     # sumsq + Adam (host schedule and device schedule)
     n = 4096 * 5
     def adam(dev):
