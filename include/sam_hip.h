@@ -71,6 +71,12 @@ int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b,
  * encoder rows never see decoder keys, so their q/k/v (and outputs) are step-invariant and stay cached in qkv / out. */
 int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
                       int head_dim, float scale, int q_begin, void* out, float* lse2, void* stream);
+/* decoding step with the decoder rows in their own buffer: qkv_enc bf16 [B*N, 3*H*64] is the cache of a full pass (only its first N - n_dec rows per
+ * sample are read: the text / object / OCR rows, step-invariant under the prefix-LM mask); qkv_dec bf16 [B*n_dec, 3*H*64] holds this step's q|k|v of
+ * the decoder rows, straight out of their QKV projection (no copy into the cache); out_dec bf16 [B*n_dec, H*64] receives the attention output of
+ * the decoder rows only.  Same arithmetic per row as sam_attn_fwd (the results are bit-identical to a full pass over the same values). */
+int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
+                     int H, int head_dim, float scale, void* out_dec, void* stream);
 /* autograd of sam_attn_fwd: dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
 int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow, int64_t allow_stride_b,
                  int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim, float scale, float p_drop,
@@ -242,6 +248,23 @@ typedef struct sam_lr_schedule {
 int sam_step_advance(unsigned long long* rng_state, uint64_t offset_stride, int64_t* step_counter, const sam_lr_schedule* sched, float* dev_sched,
                      void* stream);
 int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+
+/* ---- token selection of the decoding loops (csrc/decode.hip), on the two score blocks the model produces: classifier logits fixed [R*S, V] and
+ * pointer scores ocr [R*S, No] (fp32, row strides in elements; the reference's `scores` is their concatenation) ----
+ * sam_greedy_pick: sam/sa_m4c.py:299-302 -- prev_inds[r, s + 1] = argmax_j scores[r, s, j] for s < S - 1 (first maximum wins, as torch.argmax).
+ * sam_beam_step: one BeamSearch.decode step (sam/beam_search.py:84-160) for B samples of K beams (rows b*K .. b*K+K-1), state updated IN PLACE:
+ *   seqs int64 [B*K, S] (train_prev_inds), cum f32 [B*K] (topkscores), done u8 [B*K] (completed_ids as flags; zero before the first step);
+ *   prev_pos int64 [B*K] (may be NULL) receives each surviving beam's source row (prev_position).  Candidate score = log(sigmoid(x)) + cum[beam];
+ *   completed beams offer only EOS at log-probability 0; at step 0 only beam 0 of a sample is live; the K best of the flattened [K, V+No] axis in
+ *   descending order (lower flat index first among equals); source beam = idx / (V+No) -- INTEGER division, the reference's torch <= 1.4 `/` --,
+ *   token = idx % (V+No); cum[new] = cum[src] + value (the value already holds cum[src]: counted twice, as upstream).
+ *   ctl = NULL: the step index is `t`.  ctl = int32[4] in device memory {t, finished, 0, 0} (zero-filled before the first step): the step index is
+ *   ctl[0], advanced by the launch itself, and once every beam is complete (or the steps ran out) ctl[1] is set and later launches leave the state
+ *   untouched -- what lets ONE captured decoding step be replayed S - 1 times with the reference's early exit. */
+int sam_greedy_pick(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int R, int S, int V, int No, int64_t* prev_inds,
+                    void* stream);
+int sam_beam_step(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,
+                  int32_t* ctl, float* cum, uint8_t* done, int64_t* seqs, int64_t* prev_pos, void* stream);
 
 /* ---- dropout RNG state in device memory (hipGraph capture) ----
  * Every dropout site takes (seed, offset) BY VALUE (counter-based: the backward regenerates the forward's mask from the same pair).  Launches

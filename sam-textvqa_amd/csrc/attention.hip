@@ -35,6 +35,16 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* bas
   }
 }
 
+// decode: rows [0, n_split) come from `base`, rows [n_split, n_valid) from `base2` (row r at base2 + (r - n_split) * ld)
+__device__ __forceinline__ void stage_tile2(unsigned char* lds, const bf16_t* base, const bf16_t* base2, int n_split, int64_t ld, int n_valid, int npad, int tid) {
+  for (int c = tid; c < npad * 8; c += blockDim.x) {
+    const int row = c >> 3, ch = c & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < n_valid) v = *reinterpret_cast<const uint4*>((row < n_split ? base + (int64_t)row * ld : base2 + (int64_t)(row - n_split) * ld) + ch * 8);
+    *reinterpret_cast<uint4*>(lds + tile_off(row, ch)) = v;
+  }
+}
+
 __device__ __forceinline__ bf16x8 lds_row_frag(const unsigned char* tile, int row, int ch) {
   return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, ch));
 }
@@ -74,6 +84,12 @@ struct AttnArgs {
   const float* lse2;
   float* delta;           // [B, H, N] bwd workspace: sum_k P*dP per query row
   int B, N, H, NW, nkt, q_begin;   // q_begin: first query row to compute (forward only; rounded down to a 16-row tile)
+  // decoding (attn_fwd_kernel<NKT, true>): the q|k|v rows of the n_dec = N - n_enc decoder tokens live in their own compact buffer
+  // qkv_dec [B * n_dec, 3*H*64] (written by this step's QKV projection, no copy into the cache), the encoder rows in `qkv` as ever;
+  // only decoder rows are written, compactly, to out_dec [B * n_dec, H*64]
+  const bf16_t* qkv_dec;
+  bf16_t* out_dec;
+  int n_enc;
   float scale, scale_log2, p_drop, inv_keep;
   unsigned thr16, seed_lo, seed_hi, off_lo, off_hi;
   const unsigned long long* rng_state;
@@ -86,7 +102,7 @@ struct AttnArgs {
 // 8 waves per block (two per SIMD) instead of 4 -- with one wave per SIMD nothing hides the MFMA -> softmax -> MFMA dependency chain
 // (stress shape, B = 32: forward 88.7 us, backward 252 us at 4 waves).  The forward also runs 8 waves at 12 key tiles (two blocks = 16 waves per CU
 // instead of three blocks = 12: 34.1 -> 31.2 us with dropout at B = 64); the dQ kernel does not gain from it (77 -> 80 us) and stays at 4.
-template <int NKT>
+template <int NKT, bool DEC = false>
 __global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NPAD = NKT * 16;
@@ -96,8 +112,14 @@ __global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_f
   const int N = a.N, Dm = a.H * HD;
   const int64_t ld = 3 * (int64_t)Dm;
   const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
-  stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
-  stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  const bf16_t* dbase = DEC ? a.qkv_dec + (int64_t)b * (N - a.n_enc) * ld + h * HD : nullptr;
+  if (DEC) {
+    stage_tile2(Ks, qbase + Dm, dbase + Dm, a.n_enc, ld, N, NPAD, tid);
+    stage_tile2(Vs, qbase + 2 * Dm, dbase + 2 * Dm, a.n_enc, ld, N, NPAD, tid);
+  } else {
+    stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
+    stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  }
   __syncthreads();
 
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
@@ -107,8 +129,9 @@ __global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_f
   for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += nwaves) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     bf16x8 qf[2];
+    const bf16_t* qrow = (DEC && qc >= a.n_enc) ? dbase + (int64_t)(qc - a.n_enc) * ld : qbase + (int64_t)qc * ld;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
+    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
     unsigned aw[NKT / 2];
     const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
 #pragma unroll
@@ -181,6 +204,16 @@ __global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_f
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pl, o[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting all V fragments costs 96 VGPRs and a wave of occupancy
+    }
+    if (DEC) {
+      if (q < N && q >= a.n_enc) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          uint2 ov = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
+          *reinterpret_cast<uint2*>(a.out_dec + ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm + h * HD + 16 * dt + 4 * g) = ov;
+        }
+      }
+      continue;
     }
     if (q < N) {
 #pragma unroll
@@ -518,7 +551,41 @@ int launch_fwd(const AttnArgs& a, hipStream_t st) {
   return SAM_OK;
 }
 
+template <int NKT>
+int launch_dec(const AttnArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  attn_fwd_kernel<NKT, true><<<dim3(a.B * a.H), dim3(NKT <= 8 ? 256 : 512), lds, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 }  // namespace
+
+extern "C" int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
+                                int H, int head_dim, float scale, void* out_dec, void* stream) {
+  AttnArgs a = {};
+  int rc = fill_common(a, B, N, H, head_dim, scale, 0.f);
+  if (rc) return rc;
+  SAM_REQUIRE(qkv_enc && qkv_dec && allow && out_dec, "sam_attn_fwd_dec: null pointer");
+  SAM_REQUIRE(n_dec > 0 && n_dec < N, "sam_attn_fwd_dec: n_dec=%d outside (0,%d)", n_dec, N);
+  a.qkv = (const bf16_t*)qkv_enc; a.qkv_dec = (const bf16_t*)qkv_dec; a.out_dec = (bf16_t*)out_dec; a.n_enc = N - n_dec;
+  a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h; a.q_begin = N - n_dec;
+  hipStream_t st = (hipStream_t)stream;
+  switch (a.nkt) {
+    case 2: return launch_dec<2>(a, st);
+    case 4: return launch_dec<4>(a, st);
+    case 8: return launch_dec<8>(a, st);
+    case 12: return launch_dec<12>(a, st);
+    case 16: return launch_dec<16>(a, st);
+    case 24: return launch_dec<24>(a, st);
+  }
+  return SAM_ERR_UNSUPPORTED;
+}
 
 extern "C" int sam_attn_words_per_row(int N) {
   const int nkt = pick_nkt(N);

@@ -1,0 +1,327 @@
+"""Auto-regressive decoding at evaluation time: the greedy loop of SAM4C._forward_mmt_and_output (sam/sa_m4c.py:285-302) and the beam search of
+SAM4C._forward_beam_search + BeamSearch (sam/sa_m4c.py:304-314, sam/beam_search.py:6-181), SURVEY.md §8(f-3).
+
+What the reference does: one FULL forward of the multimodal transformer per decoding step (12 of them), `argmax` / `topk` on the host side of
+eager PyTorch in between.  Here:
+  * under the prefix-LM mask (sa_m4c.py:834-844) no text / object / OCR row ever sees a decoder key, so those rows -- and their keys / values in
+    every layer -- are the same in all steps: ONE full pass computes them, the steps re-run only the n_dec decoder rows of each layer against
+    the cached keys / values (sam_attn_fwd_dec: the decoder rows' q|k|v stay in their own compact buffer, nothing is copied into the cache);
+  * everything that does not depend on the step is computed once per batch (LayerNorm of the answer table and of the OCR rows inside
+    PrevPredEmbeddings, the pointer network's keys, every mask);
+  * the token selection is a kernel working in place on the decoder state (sam_greedy_pick / sam_beam_step), so a step needs no host decision;
+  * the first pass and the decoding step are captured as two hipGraphs over static buffers: a batch costs one input copy, one replay of the
+    first graph and n_dec - 1 replays of the second (the eager loop was bound by ~70 launches x 12 steps of host time).
+Beam search keeps the reference's structure -- every sample repeated beam_size times, candidates ranked over the flattened [beam, vocab] axis,
+surviving beams re-gathered -- and its exact arithmetic, including the quirks listed in oracle/beam_search.py (integer `indices / vocab_size`,
+cumulative scores that count the source beam twice, completed beams forced onto EOS); the re-gathering of the batch's feature tensors by
+`prev_position` (beam_search.py:131-137) permutes identical copies inside one sample's group and is therefore not executed."""
+import math
+import os
+
+import torch
+
+from . import _capi as capi
+from . import ops
+from .autograd import BF16, _fused_qkv, _padded_views, _w
+from .registry import registry
+
+BATCH_DICT_KEYS = ["pad_obj_features", "pad_obj_bboxes", "ocr_fasttext", "ocr_phoc", "pad_ocr_features", "pad_ocr_bboxes", "question_indices", "question_mask",
+                   "pad_obj_mask", "pad_ocr_mask", "spatial_adj_matrices", "ocr_mmt_in", "obj_mmt_in", "question_id"]      # sam/beam_search.py:14-29
+
+
+class BeamSearch:
+    """sam/beam_search.py:6-181 with the reference's method names; `decode` runs sam_beam_step on the GPU.  State lives in batch_dict exactly as
+    upstream (`train_prev_inds`, `topkscores`, plus `_beam_done`: the completed beams as flags instead of an index list)."""
+
+    def __init__(self, beam_size, eos_idx=None, bos_idx=None):
+        if not 1 <= int(beam_size) <= 16:
+            raise ValueError("beam_size must be in 1..16, got %r" % (beam_size,))
+        self._decode_size = int(beam_size)
+        self._EOS_IDX = registry.EOS_IDX if eos_idx is None else eos_idx
+        self._BOS_IDX = registry.BOS_IDX if bos_idx is None else bos_idx
+        if self._EOS_IDX is None:
+            raise RuntimeError("BeamSearch needs registry.EOS_IDX (sam/beam_search.py:12) or an explicit eos_idx")
+        self.completed_ids = None
+        self.batch_dict_keys = list(BATCH_DICT_KEYS)
+
+    def init_batch(self, batch_dict):
+        """beam_search.py:31-82: every sample repeated beam_size times (interleaved), cumulative scores zero"""
+        k = self._decode_size
+        self.completed_ids = None
+        prev = batch_dict["train_prev_inds"]
+        self._batch_size = prev.shape[0]
+        for key in self.batch_dict_keys + ["train_prev_inds"]:
+            if key in batch_dict:
+                v = batch_dict[key]
+                if isinstance(v, dict):
+                    batch_dict[key] = {kk: vv.repeat_interleave(k, dim=0) for kk, vv in v.items()}
+                else:
+                    batch_dict[key] = v.repeat_interleave(k, dim=0)
+        dev = batch_dict["train_prev_inds"].device
+        batch_dict["topkscores"] = torch.zeros((self._batch_size * k, 1), dtype=torch.float32, device=dev)   # (an integer zero tensor upstream until the first add)
+        batch_dict["_beam_done"] = torch.zeros(self._batch_size * k, dtype=torch.uint8, device=dev)
+        return batch_dict
+
+    def decode(self, batch_dict, t):
+        """beam_search.py:84-160 on batch_dict["scores"] (or the two blocks "fixed_scores" / "dynamic_ocr_scores"); returns (finish, batch_dict, 0)"""
+        k, b = self._decode_size, self._batch_size
+        fixed, ocr = batch_dict.get("fixed_scores"), batch_dict.get("dynamic_ocr_scores")
+        prev = batch_dict["train_prev_inds"]
+        s = prev.shape[1]
+        if fixed is None or ocr is None or fixed.dtype != torch.float32:
+            sc = batch_dict["scores"].float()
+            n_ocr = batch_dict["pad_ocr_mask"].shape[1] if "pad_ocr_mask" in batch_dict else 0
+            v = sc.shape[-1] - n_ocr
+            fixed, ocr = sc[..., :v].reshape(b * k * s, v), sc[..., v:].reshape(b * k * s, -1)
+            if ocr.shape[1] == 0:
+                ocr = sc.new_zeros((b * k * s, 1)) - float("inf")
+        fixed = fixed.reshape(b * k * s, -1)
+        ocr = ocr.reshape(b * k * s, -1)
+        if fixed.stride(1) != 1:
+            fixed = fixed.contiguous()
+        if ocr.stride(1) != 1:
+            ocr = ocr.contiguous()
+        prev = prev.contiguous()
+        cum = batch_dict["topkscores"].reshape(-1).float().contiguous()
+        done = batch_dict["_beam_done"]
+        prev_pos = torch.empty(b * k, dtype=torch.int64, device=prev.device)
+        ops.beam_step(fixed, ocr, b, k, prev, cum, done, self._EOS_IDX, t=t, prev_pos=prev_pos)
+        batch_dict["train_prev_inds"], batch_dict["topkscores"], batch_dict["prev_position"] = prev, cum.view(-1, 1), prev_pos
+        self.completed_ids = done.nonzero() if t + 1 < s else torch.arange(b * k, device=prev.device)      # beam_search.py:140-147
+        finish = bool(len(self.completed_ids) == b * k) or s == t + 1
+        if finish:
+            batch_dict["complete_seqs"] = prev[self.completed_ids, :]
+        return finish, batch_dict, 0
+
+    def find_complete_inds(self, seqs, t):
+        return (seqs[:, t] == self._EOS_IDX).nonzero()
+
+    @staticmethod
+    def add_next_word(seqs, prev_word_inds, next_word_inds, t):
+        new_seqs = seqs[prev_word_inds]
+        if t + 1 < new_seqs.shape[1]:
+            new_seqs[:, t + 1] = next_word_inds
+        return new_seqs
+
+
+def graph_enabled():
+    return os.environ.get("SAM_DECODE_GRAPH", "1") != "0"
+
+
+class DecodeSession:
+    """static buffers + the two captured graphs for one (model, input shapes, beam size)"""
+
+    def __init__(self, model, batch_dict, beam=0, eos_idx=None):
+        self.model, self.beam = model, int(beam)
+        self.eos = eos_idx
+        self.items = _flatten(batch_dict)
+        self.sig = signature(batch_dict, beam)
+        dev = next(model.parameters()).device
+        self.static = [torch.empty_like(v, device=dev) for _, _, v in self.items]
+        self.bd = {}
+        for (k, kk, _), t in zip(self.items, self.static):
+            if kk is None:
+                self.bd[k] = t
+            else:
+                self.bd.setdefault(k, {})[kk] = t
+        self.rows, self.steps = self.bd["train_prev_inds"].shape
+        self.graph_first = self.graph_step = None
+        self.pool = None
+
+    # ---- what is enqueued ------------------------------------------------------------------------------------
+    def _first(self):
+        """everything up to and including the first token selection"""
+        m, bd = self.model, dict(self.bd)
+        mmt = m.mmt
+        bd["spatial_adj_matrices"] = dict(self.bd["spatial_adj_matrices"])
+        bd["_sam_masks_u8"] = ops.pack_masks(bd["question_mask"], bd["pad_obj_mask"], bd["pad_ocr_mask"])
+        m._forward_obj_encoding(bd)
+        m._forward_ocr_encoding(bd)
+        m._forward_text_bert(bd)
+        self.enc = (bd["text_bert_emb"], bd["obj_mmt_in"], bd["ocr_mmt_in"])
+        r, s = self.rows, self.steps
+        self.prev = self.bd["train_prev_inds"]
+        if self.beam == 0:                                   # sa_m4c.py:287-291: BOS, then zeros (beam search starts from the caller's tensor)
+            self.prev.zero_()
+            self.prev[:, 0] = m.bos_idx
+        else:
+            self.cum = torch.zeros(r, dtype=torch.float32, device=self.prev.device)
+            self.done = torch.zeros(r, dtype=torch.uint8, device=self.prev.device)
+            self.ctl = torch.zeros(4, dtype=torch.int32, device=self.prev.device)
+        # PrevPredEmbeddings: the step-invariant halves (sa_m4c.py:921-927)
+        pp = mmt.prev_pred_embeddings
+        ans_w = m.classifier.weight
+        ans_x = ans_w.data if ans_w.is_contiguous() else ans_w.data.contiguous()
+        self.n_ans = ans_x.shape[0]
+        self.ans_ln = ops.layernorm_fwd(ans_x, pp.ans_layer_norm.weight, pp.ans_layer_norm.bias, pp.ans_layer_norm.variance_epsilon)[0]
+        ocr_in = bd["ocr_mmt_in"]
+        self.n_ocr = ocr_in.shape[1]
+        ocr_x = ocr_in.reshape(r * self.n_ocr, -1)
+        self.ocr_ln = ops.layernorm_fwd(ocr_x if ocr_x.is_contiguous() else ocr_x.contiguous(), pp.ocr_layer_norm.weight, pp.ocr_layer_norm.bias,
+                                        pp.ocr_layer_norm.variance_epsilon)[0]
+        x_dec = self._dec_embed()
+        d = x_dec.shape[1]
+        x = torch.cat([bd["text_bert_emb"].to(BF16), bd["obj_mmt_in"].to(BF16), bd["ocr_mmt_in"].to(BF16), x_dec.view(r, s, d)], dim=1)
+        self.n = x.shape[1]
+        n_txt, n_obj = bd["question_mask"].size(-1), bd["pad_obj_mask"].size(-1)
+        from .modules import AllowBits
+        allow = AllowBits(ops.mask_bits_prefix_lm(bd["_sam_masks_u8"][0], s))
+        self.plan = mmt.encoder._layer_plan(allow, bd, None)
+        self.ocr_mask = bd["_sam_masks_u8"][2]
+        seq2d, caches = mmt.encoder.infer_full(x.reshape(r * self.n, d).contiguous(), allow, bd, r)
+        self.caches = caches
+        self.seq = seq2d.view(r, self.n, d)
+        ocr0 = n_txt + n_obj
+        self.ocr0 = ocr0
+        ocr_rows = self.seq[:, ocr0: ocr0 + self.n_ocr].contiguous()
+        pk = m.ocr_ptr_net.key                                                  # pointer-network keys: OCR rows are step-invariant
+        wv, _, bv, _, _, _ = _padded_views(pk.weight, pk.bias)
+        self.ptr_k = ops.gemm(ocr_rows.view(r * self.n_ocr, d), wv, epilogue=capi.EPI_BIAS, bias=bv).view(r, self.n_ocr, -1)
+        y_dec = self.seq[:, self.n - s:].reshape(r * s, d)
+        self.out_first = self._head_and_pick(y_dec)
+
+    def _dec_embed(self):
+        """PrevPredEmbeddings.forward for the current train_prev_inds, eval mode (sa_m4c.py:928-948) -> bf16 [R*S, D]"""
+        pp = self.model.mmt.prev_pred_embeddings
+        r, s = self.rows, self.steps
+        is_ocr = self.prev.ge(self.n_ans).view(torch.uint8).reshape(-1)
+        e = ops.embed_sum_fwd(pp.position_embeddings.weight.data, pp.token_type_embeddings.weight.data, r * s, s, type_ids=is_ocr)
+        emb = ops.layernorm_fwd(e, pp.emb_layer_norm.weight, pp.emb_layer_norm.bias, pp.emb_layer_norm.variance_epsilon)[0]
+        return ops.gather2_add_fwd(self.ans_ln, self.ocr_ln, self.prev, self.n_ocr, emb, 0.0)
+
+    def _step(self):
+        """one decoding step: the decoder rows through every layer against the cached encoder keys / values, then the token selection"""
+        from .modules import _layer_tail
+        r, s = self.rows, self.steps
+        x = self._dec_embed()
+        for (layer, bits), (qkv_full, _, _) in zip(self.plan, self.caches):
+            att = layer.attention.self
+            wqkv, bqkv, _, _ = _fused_qkv(att)
+            qkv_dec = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
+            ctx = ops.attn_fwd_dec(qkv_full, qkv_dec, bits, r, self.n, s, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size))
+            x = _layer_tail(layer, ctx, x)
+        self.y_dec = x
+        self.out_step = self._head_and_pick(x)
+
+    def _head_and_pick(self, y_dec):
+        """classifier + pointer network on the decoder rows (sa_m4c.py:270-278), then the token selection in place on the decoder state"""
+        m = self.model
+        r, s = self.rows, self.steps
+        wv, _, bv, _, n_pad, _ = _padded_views(m.classifier.weight, m.classifier.bias)
+        fixed = ops.gemm(y_dec, wv, epilogue=capi.EPI_BIAS, bias=bv, out_dtype=torch.float32)
+        if n_pad != m.classifier.weight.shape[0]:
+            fixed = fixed[:, : m.classifier.weight.shape[0]]
+        pq = m.ocr_ptr_net.query
+        wq, _, bq, _, _, _ = _padded_views(pq.weight, pq.bias)
+        q = ops.gemm(y_dec, wq, epilogue=capi.EPI_BIAS, bias=bq).view(r, s, -1)
+        dyn = ops.ptr_scores_fwd(q, self.ptr_k, self.ocr_mask, 1.0 / math.sqrt(m.ocr_ptr_net.query_key_size))
+        dyn2 = dyn.view(r * s, -1)
+        if self.beam == 0:
+            ops.greedy_pick(fixed, dyn2, self.prev)
+        else:
+            ops.beam_step(fixed, dyn2, r // self.beam, self.beam, self.prev, self.cum, self.done, self.eos, ctl=self.ctl)
+        return fixed, dyn
+
+    # ---- running it ------------------------------------------------------------------------------------------
+    def load_inputs(self, batch_dict, force=False):
+        items = _flatten(batch_dict)
+        stale = [(dst, v) for (_, _, v), dst in zip(items, self.static) if v.data_ptr() != dst.data_ptr()]
+        if force and len(stale) != len(items):
+            raise RuntimeError("DecodeSession: the first batch must not alias the session's static buffers")
+        if stale:
+            torch._foreach_copy_([d for d, _ in stale], [v if v.device == d.device else v.to(d.device, non_blocking=True) for d, v in stale])
+
+    @torch.no_grad()
+    def run(self, batch_dict):
+        self.model._ready()
+        self.load_inputs(batch_dict)
+        if graph_enabled() and self.graph_first is None:
+            self._capture()
+            self.load_inputs(batch_dict, force=True)       # (the eager round inside _capture decoded in place on the static train_prev_inds)
+        if not graph_enabled():
+            self._first()
+            last = self.out_first
+            for _ in range(self.steps - 1):
+                self._step()
+                last = self.out_step
+        else:
+            self.graph_first.replay()
+            last = self.out_first
+            for _ in range(self.steps - 1):
+                self.graph_step.replay()
+                last = self.out_step
+        return self._results(batch_dict, last)
+
+    def _capture(self):
+        # one eager round first: lazily-set kernel attributes, workspaces, flat-storage preparation must not happen inside a capture
+        cur = torch.cuda.current_stream()
+        st = torch.cuda.Stream()
+        st.wait_stream(cur)
+        with torch.cuda.stream(st):
+            self._first()
+            if self.steps > 1:
+                self._step()
+        cur.wait_stream(st)
+        torch.cuda.synchronize()
+        g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g1, stream=st):
+            self._first()
+        self.pool = g1.pool()
+        g2 = torch.cuda.CUDAGraph()
+        if self.steps > 1:
+            with torch.cuda.graph(g2, pool=self.pool, stream=st):
+                self._step()
+        self.graph_first, self.graph_step = g1, g2
+
+    def _results(self, batch_dict, last):
+        fixed, dyn = last
+        r, s = self.rows, self.steps
+        scores = torch.cat([fixed.view(r, s, -1), dyn], dim=-1)
+        batch_dict["scores"] = scores
+        batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"] = fixed.view(r, s, -1), dyn
+        batch_dict["train_prev_inds"] = self.prev.clone()
+        batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"] = self.enc
+        seq = self.seq.clone()
+        if self.steps > 1:
+            seq[:, self.n - s:] = self.y_dec.view(r, s, -1)
+        batch_dict["mmt_seq_output"] = seq
+        n_txt = batch_dict["question_mask"].size(-1)
+        batch_dict["mmt_txt_output"], batch_dict["mmt_ocr_output"] = seq[:, :n_txt], seq[:, self.ocr0: self.ocr0 + self.n_ocr]
+        batch_dict["mmt_dec_output"] = seq[:, self.n - s:]
+        if self.beam:
+            batch_dict["topkscores"] = self.cum.clone().view(-1, 1)
+            batch_dict["complete_seqs"] = batch_dict["train_prev_inds"]           # (every beam is in `completed_ids` when the reference's loop ends)
+        return scores
+
+
+def _flatten(bd):
+    out = []
+    for k in sorted(bd):
+        v = bd[k]
+        if k.startswith("_") or k in _OUTPUT_KEYS:
+            continue
+        if torch.is_tensor(v):
+            out.append((k, None, v))
+        elif isinstance(v, dict):
+            out.extend((k, kk, vv) for kk, vv in sorted(v.items()) if torch.is_tensor(vv))
+    return out
+
+
+_OUTPUT_KEYS = {"scores", "fixed_scores", "dynamic_ocr_scores", "text_bert_emb", "obj_mmt_in", "ocr_mmt_in", "mmt_seq_output", "mmt_txt_output", "mmt_ocr_output",
+                "mmt_dec_output", "topkscores", "complete_seqs", "prev_position", "targets", "train_loss_mask"}
+
+
+def signature(batch_dict, beam):
+    return (int(beam),) + tuple((k, kk, tuple(v.shape), v.dtype) for k, kk, v in _flatten(batch_dict))
+
+
+def session_for(model, batch_dict, beam=0, eos_idx=None):
+    """the model's cached DecodeSession for these input shapes (a handful of shapes per run: full batches and the last partial one)"""
+    cache = model.__dict__.setdefault("_sam_decode_sessions", {})
+    sig = signature(batch_dict, beam) + (eos_idx,)
+    ses = cache.get(sig)
+    if ses is None:
+        if len(cache) >= 4:
+            cache.pop(next(iter(cache)))
+        ses = cache[sig] = DecodeSession(model, batch_dict, beam, eos_idx)
+    return ses

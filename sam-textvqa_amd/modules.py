@@ -735,10 +735,44 @@ class SAM4C(_HipModule):
         if bd.get("_sam_want_scores", True) or not self.training:
             bd["scores"] = torch.cat([bd["fixed_scores"], bd["dynamic_ocr_scores"]], dim=-1)
 
+    def set_beam_size(self, beam_size):
+        """sa_m4c.py:53-56"""
+        from .decoder import BeamSearch
+        self.beam_size = beam_size
+        self.bsdecoder = BeamSearch(self.beam_size, bos_idx=self.bos_idx)
+        logging.getLogger(__name__).info("Using beam size: %s", self.beam_size)
+
+    def _forward_beam_search(self, batch_dict):
+        """sa_m4c.py:304-314 + sam/beam_search.py: the batch is expanded beam_size times, then ONE full pass and n_dec - 1 captured decoding steps
+        (decoder.DecodeSession) with sam_beam_step choosing the surviving beams on the device"""
+        from .decoder import session_for
+        if self.training:
+            raise RuntimeError("beam search runs in eval mode (evaluator.py:137-160 calls model.eval() first); call .eval()")
+        if getattr(self, "bsdecoder", None) is None:
+            raise RuntimeError("call set_beam_size(k) before forward(..., use_beam_search=True) (sa_m4c.py:53-56, evaluator.py:139)")
+        bs = self.bsdecoder
+        batch_dict = bs.init_batch(batch_dict)
+        batch_dict.pop("_beam_done", None)
+        ses = session_for(self, batch_dict, beam=bs._decode_size, eos_idx=bs._EOS_IDX)
+        ses.run(batch_dict)
+        return batch_dict
+
     def forward(self, batch_dict, use_beam_search=False):
-        if use_beam_search:
-            raise NotImplementedError("beam search is disabled upstream (train.py:222-225) and out of scope")
         self._ready()
+        if use_beam_search:
+            bd = self._forward_beam_search(batch_dict)
+            if bd is not batch_dict:
+                batch_dict.update(bd)
+            res = {"textvqa_scores": batch_dict["scores"], "complete_seqs": batch_dict["complete_seqs"].squeeze(), "topkscores": batch_dict["topkscores"].squeeze()}
+            if "question_id" in batch_dict:
+                res["question_id"] = batch_dict["question_id"].squeeze()
+            return res           # sa_m4c.py:192-202
+        if not self.training and self.decode_cache and not torch.is_grad_enabled() and os.environ.get("SAM_DECODE_SESSION", "1") != "0":
+            # greedy decoding (sa_m4c.py:285-302) as one full pass + n_dec - 1 captured decoding steps over static buffers (decoder.DecodeSession);
+            # the eager loop in _forward_impl is the same arithmetic launch by launch (SAM_DECODE_SESSION=0, decode_cache=False, or with autograd on)
+            from .decoder import session_for
+            session_for(self, batch_dict).run(batch_dict)
+            return {"textvqa_scores": batch_dict["scores"]}
         if all(k in batch_dict for k in ("question_mask", "pad_obj_mask", "pad_ocr_mask")) and batch_dict["question_mask"].is_cuda:
             batch_dict["_sam_masks_u8"] = ops.pack_masks(batch_dict["question_mask"], batch_dict["pad_obj_mask"], batch_dict["pad_ocr_mask"])
         try:

@@ -155,6 +155,35 @@ def attn_fwd_rows(qkv, allow, batch, n_heads, scale, q_begin, out, lse2):
     return out
 
 
+def attn_fwd_dec(qkv_enc, qkv_dec, allow, batch, n, n_dec, n_heads, scale, out_dec=None):
+    """decoding step: decoder rows' q|k|v in their own compact buffer qkv_dec [B*n_dec, 3*H*64], encoder rows read from the full-pass cache
+    qkv_enc [B*N, 3*H*64] -> attention output of the decoder rows [B*n_dec, H*64] (sam_attn_fwd_dec)"""
+    _chk(qkv_enc, BF16, "qkv_enc"); _chk(qkv_dec, BF16, "qkv_dec"); _chk(allow, torch.int32, "allow")
+    d_model = qkv_enc.shape[1] // 3
+    if out_dec is None:
+        out_dec = torch.empty((batch * n_dec, d_model), dtype=BF16, device=qkv_enc.device)
+    sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    capi.call("sam_attn_fwd_dec", capi.ptr(qkv_enc), capi.ptr(qkv_dec), capi.ptr(allow), allow.stride(0), sh, batch, n, n_dec, n_heads, d_model // n_heads,
+              float(scale), capi.ptr(out_dec), capi.stream_handle())
+    return out_dec
+
+
+def greedy_pick(fixed, ocr, prev_inds):
+    """prev_inds[r, s + 1] = argmax over [fixed | ocr] of row (r, s), s < S - 1, in place (sa_m4c.py:299-302); fixed f32 [R*S, V], ocr f32 [R*S, No]"""
+    _chk(prev_inds, torch.int64, "prev_inds")
+    r, s = prev_inds.shape
+    capi.call("sam_greedy_pick", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), r, s, fixed.shape[1], ocr.shape[1], capi.ptr(prev_inds), capi.stream_handle())
+    return prev_inds
+
+
+def beam_step(fixed, ocr, n_samples, beam, seqs, cum, done, eos, t=0, ctl=None, prev_pos=None):
+    """one BeamSearch.decode step (sam_beam_step), state (seqs int64 [B*K, S], cum f32 [B*K], done u8 [B*K]) updated in place"""
+    _chk(seqs, torch.int64, "seqs"); _chk(cum, torch.float32, "cum"); _chk(done, torch.uint8, "done")
+    s = seqs.shape[1]
+    capi.call("sam_beam_step", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), int(n_samples), int(beam), s, fixed.shape[1], ocr.shape[1], int(eos), int(t),
+              capi.ptr(ctl), capi.ptr(cum), capi.ptr(done), capi.ptr(seqs), capi.ptr(prev_pos), capi.stream_handle())
+
+
 def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0):
     """-> dqkv bf16 [B*N, 3*H*64]."""
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv")
