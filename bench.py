@@ -393,7 +393,7 @@ def main():
         groups = model.get_optimizer_parameters(1e-4)
         flat = prepare(model, groups=[g["params"] for g in groups])
         reducer = parallel.GradReducer(flat.grad, overlap=False)
-    trainer = Trainer(model, seed=1234 + rank, use_graph=(world == 1 and not args.no_graph), reducer=reducer)
+    trainer = Trainer(model, seed=1234 + rank, use_graph=not args.no_graph, reducer=reducer)      # (N > 1: captured too when the collectives are RCCL's, trainer._dp_capturable)
     trainer.measure_comm = trainer.reducer is not None        # (N > 1, or a 1-rank group under SAM_FORCE_DIST=1)
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
 
@@ -452,6 +452,13 @@ def main():
         res["overlap"] = bool(trainer.reducer.overlap)
         res["grad_payload"] = trainer.reducer.payload
     res["step_mode"] = "hipGraph replay" if (trainer.use_graph and trainer._graph is not None) else "eager launches"
+    if trainer.reducer is not None and trainer._graph is not None:
+        # the exchange is inside the captured step, where no timing event can sit: the exposed part is measured on a few eager steps of the same trainer
+        trainer.measure_comm, trainer.use_graph = True, False
+        for _ in range(4):
+            trainer.step(clone_batch(batch))
+        res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
+        res["exposed_comm_source"] = "4 eager steps after the timed region (the timed steps replay a graph that contains the exchange)"
     if world == 1 and not args.no_secondary and os.environ.get("SAM_FORCE_DIST") != "1":
         # SURVEY 8(d)'s other rows, each a short run OUTSIDE the timed region (numbers of this process, same code path as the headline)
         sec = []

@@ -364,6 +364,19 @@ class GradBarrierFn(Function):
         return g, None
 
 
+def region_done(rid):
+    """report gradient region `rid` final to the active data-parallel reducer.  Deferred LayerNorm finalizes (the dgamma / dbeta / dbias partial
+    sums of the layer's two LayerNorm backwards) belong to the region: they are reduced first, in one batched launch."""
+    red = parallel.active_reducer
+    if rid is None or red is None:
+        return
+    if ops.LnFinalizeQueue.defer:
+        ops.LnFinalizeQueue.flush()
+        if torchops.enabled():
+            torchops.ns().ln_finalize_flush()
+    red.mark_done(rid)
+
+
 # ------------------------------------------------------------------------------------------------ encoder layer
 class EncoderLayerFn(Function):
     """One BERT-style encoder layer (spatial or plain — the difference is entirely in `allow`), forward and backward,
@@ -412,9 +425,7 @@ class EncoderLayerFn(Function):
             *saved, allow = ctx.saved_tensors
             dx = torchops.ns().encoder_layer_bwd(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch, att.num_attention_heads, ctx.scale,
                                                  ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
-            rid = getattr(layer, "_sam_region_id", None)
-            if rid is not None and parallel.active_reducer is not None:
-                parallel.active_reducer.mark_done(rid)
+            region_done(getattr(layer, "_sam_region_id", None))
             return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
         x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
         wqkv, _, dwqkv, dbqkv = _fused_qkv(att)
@@ -438,9 +449,7 @@ class EncoderLayerFn(Function):
         wgrads.append((dqkv, x, dwqkv, dbqkv))
         ops.wgrad_grouped(wgrads, accumulate=acc)
         dx = ops.gemm(dqkv, wqkv, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz1) if ctx.needs_input_grad[0] else None
-        rid = getattr(layer, "_sam_region_id", None)
-        if rid is not None and parallel.active_reducer is not None:
-            parallel.active_reducer.mark_done(rid)            # this layer's gradients are final: its bucket may go out now
+        region_done(getattr(layer, "_sam_region_id", None))     # this layer's gradients are final: its bucket may go out now
         return dx, None, None, None, None, None, None
 
 

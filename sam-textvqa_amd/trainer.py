@@ -194,9 +194,22 @@ class Trainer:
 
     def step(self, batch_dict):
         """one optimisation step; returns the (device, un-synchronised) loss tensor"""
-        if self.use_graph and self.reducer is None:
+        if self.use_graph and (self.reducer is None or self._dp_capturable()):
             return self._graph_step(batch_dict)
         return self._eager_step(batch_dict)
+
+    def _dp_capturable(self):
+        """the data-parallel step is captured like the single-GPU one -- ONE step for every N -- when its collectives can be: RCCL ("nccl") all-reduce /
+        all-gather calls are stream-capturable and the order in which the buckets leave is fixed once the regions are registered, so the captured
+        graph holds the forward, the backward with the bucket all-reduces forked onto the reducer's stream at their finality points, the join, clip
+        and Adam.  Not capturable: gloo (CPU-mediated: the 2-rank CPU / shared-GPU tests), the reducer's self-check (host comparisons), SAM_DP_GRAPH=0."""
+        red = self.reducer
+        if os.environ.get("SAM_DP_GRAPH", "1") == "0" or red.check or not red.overlap or not parallel.dist.is_initialized():
+            return False
+        try:
+            return parallel.dist.get_backend(red.group) == "nccl"
+        except Exception:
+            return False
 
     def _eager_step(self, batch_dict, sched_dev=None):
         """everything one step enqueues.  sched_dev: device tensor [lr per group, 1 - beta1^t, 1 - beta2^t]; given, the optimizer kernel reads the
@@ -224,9 +237,9 @@ class Trainer:
             work.wait()
         loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, global_count=c_global)
         # the encoder layers' LayerNorm backwards leave their dgamma / dbeta / dbias partial sums in place; ONE launch reduces all of them after the
-        # backward pass (26 finalize launches of ~6 us each otherwise).  Not under a reducer: there a layer's gradients must be final when its
-        # region is marked.
-        defer_ln = self.defer_ln and self.reducer is None
+        # backward pass (26 finalize launches of ~6 us each otherwise).  Under a reducer a layer's gradients must be final when its region is
+        # marked: the queue is then flushed at every mark (autograd.region_done: one batched launch per layer instead of two finalizes).
+        defer_ln = self.defer_ln
         if defer_ln:
             self._set_ln_defer(True)
         try:
@@ -247,11 +260,12 @@ class Trainer:
         if defer_ln:
             self._ln_flush()
         if self.reducer is not None:
-            if self.measure_comm:
+            timing = self.measure_comm and not torch.cuda.is_current_stream_capturing()      # (timing events cannot be recorded into a capture)
+            if timing:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             self.reducer.finish()                               # waits for the overlapped all-reduces
-            if self.measure_comm:
+            if timing:
                 e1.record()
                 self._comm_events.append((e0, e1))
         ops.sumsq(flat.grad, self.gnorm_sq)                    # global norm AFTER the all-reduce, as the reference clips reduced grads

@@ -128,3 +128,52 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
     assert "exposed_comm_ms" in out and out["exposed_comm_ms"] >= 0.0
+
+
+_GRAPH_DP_SCRIPT = r"""
+import os, sys, torch
+sys.path.insert(0, os.environ["SAM_REPO"])
+from tests.test_model_gpu import _small_full_model
+from sam_textvqa_amd import parallel
+from sam_textvqa_amd.synthetic import clone_batch, make_batch
+from sam_textvqa_amd.trainer import Trainer
+os.environ["SAM_FORCE_DIST"] = "1"
+parallel.init_distributed()                               # 1-rank RCCL group
+res = []
+for mode in ("dp_graph", "dp_eager", "plain_graph"):
+    os.environ["SAM_FORCE_DIST"] = "0" if mode == "plain_graph" else "1"
+    model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+    tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=mode != "dp_eager")
+    assert (tr.reducer is not None) == (mode != "plain_graph")
+    if mode == "dp_graph":
+        assert tr._dp_capturable()
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    losses = [tr.step(clone_batch(batch)).item() for _ in range(6)]
+    if mode != "dp_eager":
+        assert tr._graph is not None, "the step was not captured"
+    if mode == "dp_graph":
+        assert tr.reducer.late_buckets == 0 and all(tr.reducer.done)       # (state of the capture pass: every bucket left at a finality mark)
+    res.append((losses, tr.flat.flat.clone()))
+torch.cuda.synchronize()
+(lg, pg), (le, pe), (lp, pp) = res
+print("LOSSES", lg, le, lp)
+for other in (le, lp):
+    assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(lg, other)), (lg, other)
+assert (pg - pe).abs().max().item() < 7e-3 and (pg - pp).abs().max().item() < 7e-3
+print("GRAPH_DP_OK")
+"""
+
+
+def test_data_parallel_step_is_captured_and_trains_like_the_plain_step():
+    """ONE step for every N: with RCCL collectives the data-parallel step (count all-reduce, bucket all-reduces forked onto the reducer stream at
+    their finality marks, row-sparse table exchange, join, clip, Adam) is captured into the same kind of hipGraph as the single-GPU step and
+    replayed; it trains like the eager data-parallel step and like the plain captured step (1-rank group: the sums are identities)"""
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("SAM_REDUCER_CHECK", None)
+    r = subprocess.run([sys.executable, "-c", _GRAPH_DP_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0 and "GRAPH_DP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
