@@ -30,6 +30,7 @@ struct GemmArgs {
   float* bias_grad;   // wgrad only: bias_grad[m] += sum_k A(m,k)  (column sums of dy), from the A tile already in LDS
   int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
   int* split_used;    // host pointer: receives the split factor actually launched
+  int stagger;        // gemm4 kernels: start delay of the second block slot of every CU, in units of ~3.7 us (s_sleep 127)
   int dbg;            // tuning experiments only (SAM_GEMM8_DBG; results are garbage): 1 = gemm8 kernels skip the epilogue, 2 = every tile's epilogue
                       // lands on the first tile row (outputs / residual / auxiliary rows stay in the L2: the epilogue without its HBM traffic)
 };
@@ -307,6 +308,8 @@ inline int device_cu_count() {
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.
 int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
+// two 4-wave blocks per CU, 256 x 128 x 32 tiles (gemm4.hip): force_tile 2256, or chosen by gemm8_launch where it measured faster
+int gemm4_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, hipStream_t st);
 // grouped weight gradients on the 8-wave core (gemm8w.hip): 256x256 tiles, the K range of each tile split over a PAIR of blocks that exchange
 // halves inside the launch.  descs[0].ws / ws_bytes: the exchange workspace (gemm8w_ws_bytes(total tiles); its first words are the pair flags,
 // which must be zero before the first launch and are left zero by every launch).  SAM_ERR_UNSUPPORTED: not a problem set for this kernel.
