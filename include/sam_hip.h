@@ -220,6 +220,23 @@ int sam_gather2_add_fwd(const void* ans, int64_t ld_ans, int V, const void* ocr,
 int sam_gather2_add_bwd(const void* dy, int64_t ldd, int V, int n_ocr, const int64_t* inds, int B, int S, int D, float* d_ans, int64_t ld_dans,
                         float* d_ocr, int64_t ld_docr, float p_drop, uint64_t seed, uint64_t offset, void* d_emb, int64_t ld_demb, void* stream);
 
+/* ---- tail of the object / OCR input encoders, sam/sa_m4c.py:204-224 and :226-263: out = dropout(LN_a(za) + LN_b(bbox W_b^T + b_b)) (csrc/encoder_in.hip) ----
+ * za bf16 [R, D] = the wide feature projection feat W_a^T + b_a (a sam_gemm_bf16 call); bbox fp32 [R, ldbox >= 4]: the four box coordinates, read in
+ * place from the batch's pad_{obj,ocr}_bboxes rows and rounded to bf16 as the GEMM operand was; wb bf16 [D, ldw] (the 4 -> D weight, rows padded), bias_b,
+ * gamma / beta of the two BertLayerNorms (eps inside the sqrt), hidden-state dropout stream on (row, col/8) under (seed, offset).  ONE launch forward
+ * (upstream: six eager ops; the round-2 path: box pack + box GEMM + two LayerNorms + add/dropout).  stats f32 [R, 4] = (mean_a, rstd_a, mean_b, rstd_b).
+ * Backward: ONE row pass (dropout mask regenerated, both LayerNorm backwards, z_b recomputed from the boxes) writes d za bf16 [R, D] -- the operand
+ * of the wide weight gradient -- and per-block partial column sums; a fixed-order finalize then (+)= d gamma_a, d beta_a, d gamma_b, d beta_b,
+ * d bias_b, d wb (fp32 [D, ldgw], columns 0..3).  ws: sam_input_encoder_bwd_ws_bytes(R, D). */
+int sam_input_encoder_fwd(const void* za, int64_t ldza, const float* bbox, int64_t ldbox, const void* wb, int64_t ldw, const float* bias_b,
+                          const float* gamma_a, const float* beta_a, const float* gamma_b, const float* beta_b, float eps, int R, int D, float p_drop,
+                          uint64_t seed, uint64_t offset, void* out, int64_t ldo, float* stats, void* stream);
+int64_t sam_input_encoder_bwd_ws_bytes(int R, int D);
+int sam_input_encoder_bwd(const void* dy, int64_t ldd, const void* za, int64_t ldza, const float* bbox, int64_t ldbox, const void* wb, int64_t ldw,
+                          const float* bias_b, const float* gamma_a, const float* gamma_b, const float* stats, int R, int D, float p_drop, uint64_t seed,
+                          uint64_t offset, void* dza, int64_t ldo, float* dgamma_a, float* dbeta_a, float* dgamma_b, float* dbeta_b, float* dbias_b, float* dwb,
+                          int64_t ldgw, int accumulate, float* ws, void* stream);
+
 /* ---- optimizer step over ONE flat fp32 parameter buffer: clip_grad_norm_ + Adam, train.py:139-142, task_utils.py:33-57 ----
  * sam_sumsq_f32: out[0] = sum g^2 (deterministic two-stage; every data-parallel rank gets the identical value).
  * sam_adam_step: torch.optim.Adam semantics (bias-corrected, eps outside the sqrt); per-segment learning rates

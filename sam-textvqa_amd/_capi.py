@@ -67,12 +67,15 @@ SIGNATURES = {
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],
     "sam_set_rng_state": [_vp],
     "sam_step_advance": [_vp, _u64, _vp, C.c_void_p, _vp, _vp],
+    "sam_input_encoder_fwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _i, _i, _f, _u64, _u64, _vp, _i64, _vp, _vp],
+    "sam_input_encoder_bwd_ws_bytes": [_i, _i],
+    "sam_input_encoder_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
     "sam_attn_fwd_dec": [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "sam_greedy_pick": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
     "sam_beam_step": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
-RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes"}
+RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes"}
 
 _lib = None
 

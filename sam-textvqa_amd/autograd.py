@@ -307,38 +307,38 @@ def dropout(x, p_drop, training):
 
 class InputEncoderFn(Function):
     """dropout(LN_a(feat W_a^T + b_a) + LN_b(bbox W_b^T + b_b)): the object / OCR input encoder (sam/sa_m4c.py:213-224, 252-263) as ONE autograd
-    node -- five launches forward, five backward (dropout mask regenerated, two LayerNorm backwards, two weight gradients; the inputs are
-    features, nothing flows further upstream).  A single node so that, for data parallelism, the end of its backward IS the point at which
-    the eight parameters' gradients are final (`owner._sam_region_id`, parallel.GradReducer.mark_done)."""
+    node of two launches forward (the wide projection as a GEMM; the 4 -> 768 box projection, both LayerNorms, the sum and the dropout in
+    sam_input_encoder_fwd) and three backward (sam_input_encoder_bwd = one row pass + a fixed-order finalize of the eight small gradients, then the
+    wide weight gradient with its bias gradient fused); the inputs are features, nothing flows further upstream.  A single node so that, for data
+    parallelism, the end of its backward IS the point at which the eight parameters' gradients are final (`owner._sam_region_id`).
+    feat: bf16 [R, K_pad] (ops.l2norm_pack); bbox: fp32 [R, >= 4], read in place from the batch (row stride free)."""
 
     @staticmethod
     def forward(ctx, anchor, feat, bbox, lin_a, ln_a, lin_b, ln_b, p_drop, owner):
         wa, _, ba, _, na, _ = _padded_views(lin_a.weight, lin_a.bias)
         wb, _, bb, _, nb, _ = _padded_views(lin_b.weight, lin_b.bias)
-        if feat.shape[1] != wa.shape[1] or bbox.shape[1] != wb.shape[1] or na != lin_a.weight.shape[0] or nb != lin_b.weight.shape[0]:
-            raise capi.SamHipError("InputEncoderFn: operands must arrive K-padded (ops.l2norm_pack) and out_features must be a multiple of 8")
+        if feat.shape[1] != wa.shape[1] or na != lin_a.weight.shape[0] or nb != lin_b.weight.shape[0] or lin_b.weight.shape[1] != 4:
+            raise capi.SamHipError("InputEncoderFn: the feature operand must arrive K-padded (ops.l2norm_pack), out_features must be a multiple of 8, the box projection 4 -> D")
+        if bbox.dtype != torch.float32 or bbox.stride(1) != 1:
+            bbox = bbox.float().contiguous()
         za = ops.gemm(feat, wa, epilogue=capi.EPI_BIAS, bias=ba)
-        zb = ops.gemm(bbox, wb, epilogue=capi.EPI_BIAS, bias=bb)
-        ya, mean_a, rstd_a = ops.layernorm_fwd(za, ln_a.weight, ln_a.bias, ln_a.variance_epsilon)
-        yb, mean_b, rstd_b = ops.layernorm_fwd(zb, ln_b.weight, ln_b.bias, ln_b.variance_epsilon)
         ctx.seed = dropout_clock.next() if p_drop > 0 else (0, 0)
-        out = ops.add_dropout(ya, yb, p_drop, *ctx.seed)
-        ctx.save_for_backward(feat, bbox, za, mean_a, rstd_a, zb, mean_b, rstd_b)
+        out, stats = ops.input_encoder_fwd(za, bbox, wb, bb, ln_a, ln_b, p_drop, *ctx.seed)
+        ctx.save_for_backward(feat, bbox, za, stats)
         ctx.mods, ctx.p_drop, ctx.owner = (lin_a, ln_a, lin_b, ln_b), p_drop, owner
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        feat, bbox, za, mean_a, rstd_a, zb, mean_b, rstd_b = ctx.saved_tensors
+        feat, bbox, za, stats = ctx.saved_tensors
         lin_a, ln_a, lin_b, ln_b = ctx.mods
         dy2 = dy.reshape(-1, dy.shape[-1])
-        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 8 or dy2.data_ptr() % 16:
+        if dy2.dtype != BF16 or dy2.stride(1) != 1 or dy2.stride(0) % 4 or dy2.data_ptr() % 8:
             dy2 = dy2.to(BF16).contiguous()
-        g = ops.add_dropout(dy2, None, ctx.p_drop, *ctx.seed) if ctx.p_drop > 0 else dy2
-        for lin, ln, x, z, mean, rstd in ((lin_a, ln_a, feat, za, mean_a, rstd_a), (lin_b, ln_b, bbox, zb, mean_b, rstd_b)):
-            dz, _ = ops.layernorm_bwd(g, z, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
-            _, gv, _, dbv, _, _ = _padded_views(lin.weight, lin.bias)
-            ops.gemm(dz, x, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)        # dW += dz^T x ; db += colsum(dz)
+        _, gva, _, dba, _, _ = _padded_views(lin_a.weight, lin_a.bias)
+        wb, gvb, bb, dbb, _, _ = _padded_views(lin_b.weight, lin_b.bias)
+        dza = ops.input_encoder_bwd(dy2, za, bbox, wb, bb, ln_a, ln_b, stats, gvb, dbb, ctx.p_drop, *ctx.seed)
+        ops.gemm(dza, feat, a_kcontig=False, b_kcontig=False, out=gva, accumulate=True, split_k=-1, bias_grad=dba)        # dW_a += dza^T feat ; db_a += colsum(dza)
         rid = getattr(ctx.owner, "_sam_region_id", None)
         if rid is not None and parallel.active_reducer is not None:
             parallel.active_reducer.mark_done(rid)

@@ -676,7 +676,7 @@ class SAM4C(_HipModule):
 
     def _forward_obj_encoding(self, bd):
         feat = _pack_features([bd["pad_obj_features"]], self.normalize, 0)
-        bbox = _pack_features([bd["pad_obj_bboxes"][:, :, :-1]], False, 0)
+        bbox = bd["pad_obj_bboxes"]                       # [B, n, 5]: the first four columns are read in place by the fused encoder tail
         x = self._input_encoder(feat, bbox, self.linear_obj_feat_to_mmt_in, self.obj_feat_layer_norm, self.linear_obj_bbox_to_mmt_in, self.obj_bbox_layer_norm,
                                 self.obj_drop_p, feat.shape[1])
         bd["obj_mmt_in"] = GradBarrierFn.apply(x, "obj") if self.training and torch.is_grad_enabled() else x
@@ -686,7 +686,7 @@ class SAM4C(_HipModule):
         assert ft.size(-1) == 300 and ph.size(-1) == 604
         # FastText | PHOC | FRCN | 50 legacy all-zero order columns (sa_m4c.py:242), normalised and packed into the K-padded GEMM operand
         feat = _pack_features([ft, ph, fc] if self.mmt_config.use_phoc_fasttext else [fc], self.normalize, 50)
-        bbox = _pack_features([bd["pad_ocr_bboxes"][:, :, :-1]], False, 0)
+        bbox = bd["pad_ocr_bboxes"]
         x = self._input_encoder(feat, bbox, self.linear_ocr_feat_to_mmt_in, self.ocr_feat_layer_norm, self.linear_ocr_bbox_to_mmt_in, self.ocr_bbox_layer_norm,
                                 self.ocr_drop_p, feat.shape[1])
         bd["ocr_mmt_in"] = GradBarrierFn.apply(x, "ocr") if self.training and torch.is_grad_enabled() else x

@@ -333,6 +333,34 @@ def add_dropout(a, b, p_drop, seed=0, offset=0):
     return out
 
 
+def input_encoder_fwd(za, bbox, wb, bias_b, ln_a, ln_b, p_drop=0.0, seed=0, offset=0):
+    """dropout(LN_a(za) + LN_b(bbox W_b^T + b_b)) -> (out bf16 [R, D], stats f32 [R, 4]); za bf16 [R, D], bbox fp32 [R, >= 4] (row stride free),
+    wb bf16 [D, ldw] (sam_input_encoder_fwd)"""
+    _chk(za, BF16, "za")
+    if not bbox.is_cuda or bbox.dtype != torch.float32 or bbox.dim() != 2 or bbox.stride(1) != 1 or bbox.shape[1] < 4:
+        raise capi.SamHipError("input_encoder_fwd: bbox must be a 2-D fp32 GPU tensor with >= 4 contiguous columns")
+    r, d = za.shape
+    out = torch.empty((r, d), dtype=BF16, device=za.device)
+    stats = torch.empty((r, 4), dtype=torch.float32, device=za.device)
+    capi.call("sam_input_encoder_fwd", capi.ptr(za), za.stride(0), capi.ptr(bbox), bbox.stride(0), capi.ptr(wb), wb.stride(0), capi.ptr(bias_b), capi.ptr(ln_a.weight),
+              capi.ptr(ln_a.bias), capi.ptr(ln_b.weight), capi.ptr(ln_b.bias), float(ln_a.variance_epsilon), r, d, float(p_drop), int(seed), int(offset), capi.ptr(out),
+              out.stride(0), capi.ptr(stats), capi.stream_handle())
+    return out, stats
+
+
+def input_encoder_bwd(dy, za, bbox, wb, bias_b, ln_a, ln_b, stats, dwb, dbias_b, p_drop=0.0, seed=0, offset=0, accumulate=True):
+    """-> d za bf16 [R, D]; d gamma / d beta of both LayerNorms, d bias_b and d wb (fp32 [D, ldgw] view, columns 0..3) are accumulated in place"""
+    _chk(dy, BF16, "dy")
+    r, d = za.shape
+    dza = torch.empty((r, d), dtype=BF16, device=za.device)
+    ws = _workspace(capi.call("sam_input_encoder_bwd_ws_bytes", r, d), za.device, "enc_in")
+    capi.call("sam_input_encoder_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(za), za.stride(0), capi.ptr(bbox), bbox.stride(0), capi.ptr(wb), wb.stride(0), capi.ptr(bias_b),
+              capi.ptr(ln_a.weight), capi.ptr(ln_b.weight), capi.ptr(stats), r, d, float(p_drop), int(seed), int(offset), capi.ptr(dza), dza.stride(0),
+              capi.ptr(ln_a.weight.grad), capi.ptr(ln_a.bias.grad), capi.ptr(ln_b.weight.grad), capi.ptr(ln_b.bias.grad), capi.ptr(dbias_b), capi.ptr(dwb), dwb.stride(0),
+              int(bool(accumulate)), capi.ptr(ws), capi.stream_handle())
+    return dza
+
+
 def colsum(x, out, accumulate=True):
     """out[n] (+)= sum_m x[m,n]  (x bf16 [M,N], out fp32 [N])"""
     m, n = x.shape

@@ -209,11 +209,14 @@ def test_add_dropout_kernel_mask_scale_and_backward_consistency():
     assert torch.equal(ops.add_dropout(v, None, 0.0), v)
 
 
-def test_input_encoder_node_matches_the_unfused_chain():
-    """InputEncoderFn = dropout(LN(feat W^T + b) + LN(bbox W^T + b)) as one autograd node: with dropout off, output and all eight parameter
-    gradients equal the chain of LinearFn / LayerNormFn nodes it replaces (same kernels, same order of accumulation)"""
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_input_encoder_node_matches_fp32_reference(p_drop):
+    """InputEncoderFn = dropout(LN_a(feat W_a^T + b_a) + LN_b(bbox W_b^T + b_b)), sa_m4c.py:213-224 / 252-263: the wide projection as a GEMM, the rest in
+    sam_input_encoder_fwd / _bwd.  Output and all eight parameter gradients against fp32 autograd on the same bf16-rounded operands (z_a rounded to
+    bf16 where the GEMM stores it); with dropout the mask is read off the output (zeros) and must be the hidden-state stream's mask for (seed, offset)"""
     import sam_textvqa_amd.modules as M
-    from sam_textvqa_amd.autograd import InputEncoderFn, layer_norm, linear
+    from sam_textvqa_amd import ops
+    from sam_textvqa_amd.autograd import InputEncoderFn, dropout_clock
     from sam_textvqa_amd.params import prepare
     import torch.nn as nn
 
@@ -227,17 +230,58 @@ def test_input_encoder_node_matches_the_unfused_chain():
     with torch.no_grad():
         for ln in (enc.na, enc.nb):
             ln.weight.add_(0.1 * torch.randn_like(ln.weight)); ln.bias.add_(0.1 * torch.randn_like(ln.bias))
+        enc.lb.bias.add_(0.05 * torch.randn_like(enc.lb.bias))
     fp = prepare(enc)
     g = torch.Generator().manual_seed(1)
-    feat = torch.randn(300, 2048, generator=g).to(torch.bfloat16).cuda()
-    bbox = torch.zeros(300, 8, dtype=torch.bfloat16).cuda(); bbox[:, :4] = torch.rand(300, 4, generator=g).to(torch.bfloat16).cuda()
-    gout = torch.randn(300, 768, generator=g).to(torch.bfloat16).cuda()
+    R = 1003                                                                         # not a multiple of the rows per block
+    feat = torch.randn(R, 2048, generator=g).to(torch.bfloat16).cuda()
+    boxes = torch.rand(R, 5, generator=g).cuda()                                     # [x1, y1, x2, y2, area] rows as the batch carries them: 4 are read
+    gout = torch.randn(R, 768, generator=g).to(torch.bfloat16).cuda()
     fp.zero_grad()
-    y1 = layer_norm(linear(feat, enc.la), enc.na) + layer_norm(linear(bbox, enc.lb), enc.nb)
-    y1.backward(gout)
-    g1 = fp.grad.clone()
-    fp.zero_grad()
-    y2 = InputEncoderFn.apply(enc.la.weight, feat, bbox, enc.la, enc.na, enc.lb, enc.nb, 0.0, enc.la)
+    dropout_clock.manual_seed(77)
+    y = InputEncoderFn.apply(enc.la.weight, feat, boxes, enc.la, enc.na, enc.lb, enc.nb, p_drop, enc.la)
+    y.backward(gout)
+    seed, offset = dropout_clock.seed, dropout_clock.offset
+    # fp32 reference
+    wa = enc.la.weight.detach().to(torch.bfloat16).float().requires_grad_(True); ba = enc.la.bias.detach().clone().requires_grad_(True)
+    wb = enc.lb.weight.detach().to(torch.bfloat16).float().requires_grad_(True); bb = enc.lb.bias.detach().clone().requires_grad_(True)
+    ga, bta = enc.na.weight.detach().clone().requires_grad_(True), enc.na.bias.detach().clone().requires_grad_(True)
+    gb, btb = enc.nb.weight.detach().clone().requires_grad_(True), enc.nb.bias.detach().clone().requires_grad_(True)
+
+    def ln(x, gam, bet):
+        mu = x.mean(-1, keepdim=True)
+        return (x - mu) / torch.sqrt(((x - mu) ** 2).mean(-1, keepdim=True) + 1e-12) * gam + bet
+    za = feat.float() @ wa.t() + ba
+    # the GEMM stores z_a in bf16: its OWN rounding is used (another summation order flips bf16 ties: one ulp of |z_a| ~ 4 is 0.03), straight-through for the gradient
+    from sam_textvqa_amd.autograd import _padded_views
+    wv, _, bv, _, _, _ = _padded_views(enc.la.weight, enc.la.bias)
+    za_gpu = ops.gemm(feat, wv, epilogue=1, bias=bv).float()
+    assert (za_gpu - za.detach()).abs().max().item() <= 2.0 ** -7 * za.detach().abs().max().item()
+    za = za + (za_gpu - za.detach())
+    zb = boxes[:, :4].to(torch.bfloat16).float() @ wb.t() + bb
+    pre = ln(za, ga, bta) + ln(zb, gb, btb)
+    if p_drop > 0:
+        keep_q = 1.0 - round(p_drop * 65536) / 65536.0
+        mask = (ops.add_dropout(torch.ones(R, 768, dtype=torch.bfloat16, device="cuda"), None, p_drop, seed, offset) != 0).float()
+        assert abs(mask.mean().item() - (1 - p_drop)) < 0.01
+        ref = pre * mask / keep_q
+        assert torch.equal((y != 0).float(), mask) or ((y == 0).float() - (1 - mask)).abs().sum() <= 3          # (an exact 0.0 before the mask is possible)
+    else:
+        ref = pre
+    assert_close_bf16(y, ref.detach(), name="encoder out")
+    ref.backward(gout.float())
+
+    def close(got, want, name, frac=2e-3):
+        err = (got.float() - want).abs().max().item()
+        assert err <= frac * want.abs().max().item() + 1e-6, (name, err, want.abs().max().item())
+    close(enc.na.weight.grad, ga.grad, "d gamma_a"); close(enc.na.bias.grad, bta.grad, "d beta_a")
+    close(enc.nb.weight.grad, gb.grad, "d gamma_b"); close(enc.nb.bias.grad, btb.grad, "d beta_b")
+    close(enc.lb.bias.grad, bb.grad, "d b_b"); close(enc.lb.weight.grad, wb.grad, "d W_b")
+    close(enc.la.bias.grad, ba.grad, "d b_a", 4e-3); close(enc.la.weight.grad, wa.grad, "d W_a", 4e-3)           # (through d z_a rounded to bf16)
+    # a second backward pass accumulates (the Trainer zero-fills these gradients per step)
+    before = enc.lb.weight.grad.clone()
+    dropout_clock.manual_seed(77)
+    y2 = InputEncoderFn.apply(enc.la.weight, feat, boxes, enc.la, enc.na, enc.lb, enc.nb, p_drop, enc.la)
     y2.backward(gout)
-    assert torch.equal(y1, y2)
-    assert torch.equal(g1, fp.grad)
+    assert torch.equal(y2, y)
+    close(enc.lb.weight.grad, 2 * before, "accumulated d W_b", 1e-5)
