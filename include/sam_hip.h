@@ -187,11 +187,14 @@ int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld_s, const v
 /* ---- word-embedding backward (BertEmbeddings.word_embeddings of TextBert, sam/sa_m4c.py:377,383): grad[idx[t],:] += dy[t,:] ----
  * dy bf16 [T,D]; idx int64 [T]; grad fp32 [rows, ldg]; rows outside [0,rows) and row == padding_idx (nn.Embedding semantics; -1 = none)
  * are skipped.  fp32 atomics (rows may repeat). */
-int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream);
+int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, uint8_t* touched,
+                      void* stream);
 /* the same sum in a FIXED order for an index list sorted ascending (one writer per table row, no atomics): what the data-parallel row-sparse
  * exchange uses, so that every rank adds up bit-identical gradients from the same gathered list */
 int sam_embedding_bwd_sorted(const void* dy, int64_t ldd, const int64_t* idx_sorted, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
-                             void* stream);
+                             uint8_t* touched, void* stream);
+/* `touched` (both forms; may be NULL): uint8 [rows], touched[r] := 1 for every table row that receives a gradient -- the row flags of a
+ * sam_sparse_rows region (below), which let the norm and the optimizer skip rows that never have. */
 
 /* ---- front end: feature normalisation + packing, embedding sums, previous-prediction gather (csrc/embed.hip) ----
  * sam_l2norm_pack_bf16: F.normalize(x, dim=-1) (x / max(||x||_2, eps); normalize = 0: plain cast) of fp32 rows [M, D], rounded to bf16 and
@@ -242,14 +245,21 @@ int sam_input_encoder_bwd(const void* dy, int64_t ldd, const void* za, int64_t l
  * sam_adam_step: torch.optim.Adam semantics (bias-corrected, eps outside the sqrt); per-segment learning rates
  * (param groups of SAM4C.get_optimizer_parameters, sa_m4c.py:349-371); gradient pre-scaled by
  * min(1, max_norm / (sqrt(gnorm_sq[0]) + 1e-6)) when gnorm_sq != NULL; also refreshes the bf16 shadow weights. */
+/* Row-sparse region (optional, NULL = none): elements [lo, hi) of the flat buffers form rows of row_len elements -- the 30522 x 768 word-embedding
+ * table of TextBert, a quarter of all parameters, of which one step touches at most B * 20 rows.  A row whose flag is 0 has NEVER received a gradient:
+ * g = exp_avg = exp_avg_sq = 0 there, so torch.optim.Adam's update is exactly zero and its squares add nothing to the norm; such rows are skipped
+ * (results bit-identical to the dense pass, 0.7 GB less traffic per step while few rows are in use).  The optimizer clears the gradient of the
+ * touched rows after using it: the region is never zero-filled, untouched rows stay zero for ever.  Flags are set by sam_embedding_bwd[_sorted];
+ * a caller that installs optimizer state from elsewhere (checkpoint) must set the flags of every row whose state is non-zero. */
+typedef struct sam_sparse_rows { int64_t lo, hi; int32_t row_len; const uint8_t* touched; } sam_sparse_rows;
 int64_t sam_sumsq_ws_bytes(void);
-int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, void* stream);
-int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
-                  float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream);
+int sam_sumsq_f32(const float* g, int64_t n, const sam_sparse_rows* sparse, float* out, float* ws, void* stream);
+int sam_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                  float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream);
 /* the same update with the step's schedule in DEVICE memory: dev_sched = [lr of segment 0..nseg-1, 1 - beta1^t, 1 - beta2^t] (fp32).  A launch
  * captured in a hipGraph freezes its by-value arguments; this form lets every replay apply the current learning rates / bias corrections. */
-int sam_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
-                      float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, void* stream);
+int sam_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                      float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream);
 /* Per-step state of a hipGraph-captured training step, advanced ON THE DEVICE by the graph's first node (nothing the host writes is read by
  * a replay, so the host may queue replays as far ahead as it likes):
  *   rng_state[1] += offset_stride (fresh dropout masks; rng_state = the array given to sam_set_rng_state, may be NULL);

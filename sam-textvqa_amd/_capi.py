@@ -50,8 +50,8 @@ SIGNATURES = {
     "sam_bce_loss": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _i64, _vp, _i64, _vp],
     "sam_ptr_scores_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _i64, _i64, _vp],
     "sam_ptr_scores_bwd": [_vp, _i64, _i64, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp],
-    "sam_embedding_bwd": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
-    "sam_embedding_bwd_sorted": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp],
+    "sam_embedding_bwd": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp],
+    "sam_embedding_bwd_sorted": [_vp, _i64, _vp, _i, _i, _i, _i64, _vp, _i64, _vp, _vp],
     "sam_l2norm_pack_bf16": [_vp, _i64, _i, _i, _i, _f, _vp, _i64, _i, _i, _vp],
     "sam_embed_sum_fwd": [_vp, _i64, _vp, _i, _vp, _i64, _i, _vp, _i64, _vp, _i, _i, _i, _vp, _i64, _vp],
     "sam_embed_sum_bwd_ws_bytes": [_i, _i, _i],
@@ -59,9 +59,9 @@ SIGNATURES = {
     "sam_gather2_add_fwd": [_vp, _i64, _i, _vp, _i64, _i, _vp, _i, _i, _i, _vp, _i64, _f, _u64, _u64, _vp, _i64, _vp],
     "sam_gather2_add_bwd": [_vp, _i64, _i, _i, _vp, _i, _i, _i, _vp, _i64, _vp, _i64, _f, _u64, _u64, _vp, _i64, _vp],
     "sam_sumsq_ws_bytes": [],
-    "sam_sumsq_f32": [_vp, _i64, _vp, _vp, _vp],
-    "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, _vp],
-    "sam_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, _vp],
+    "sam_sumsq_f32": [_vp, _i64, C.c_void_p, _vp, _vp, _vp],
+    "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, C.c_void_p, _vp],
+    "sam_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, C.c_void_p, _vp],
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "sam_pack_masks_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],
@@ -78,6 +78,11 @@ NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_gr
 RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes"}
 
 _lib = None
+
+
+class SparseRows(C.Structure):
+    """mirror of `sam_sparse_rows` (include/sam_hip.h)"""
+    _fields_ = [("lo", _i64), ("hi", _i64), ("row_len", C.c_int32), ("touched", _vp)]
 
 
 class LrSchedule(C.Structure):

@@ -448,14 +448,32 @@ __global__ __launch_bounds__(256) void ptr_bwd_kernel(const float* ds, int64_t l
 }
 
 // ------------------------------------------------------------------------------------------ optimizer
-constexpr int SUMSQ_BLOCKS = 1024;
-__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, int64_t n, float* partial) {
+constexpr int SUMSQ_BLOCKS = 1024, SPARSE_ROW_BLOCKS = 256;
+// A row-sparse region of the flat buffers (the word-embedding table: 30522 x 768 of the 96.6 M parameters, of which a step touches at most B * 20
+// rows): rows [lo, hi) / row_len whose `touched` flag is 0 have NEVER received a gradient -- g = m = v = 0 there, Adam's update is exactly zero and
+// their squares add nothing to the norm, so they are skipped (bit-identical to the dense pass).  The dense kernels walk the rest of the buffer
+// through an index remap; the last SPARSE_ROW_BLOCKS blocks of the same launch walk the flagged rows.
+struct SparseRows { int64_t lo4, hi4; int row_len4, rows; const unsigned char* touched; };      // (float4 units)
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, int64_t n, SparseRows sp, int dense_blocks, float* partial) {
   __shared__ float sred[4];
   float acc = 0.f;
   const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(g)[i];
-    acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  if ((int)blockIdx.x < dense_blocks) {
+    const int64_t gap = sp.hi4 - sp.lo4, n4d = n4 - gap;
+    for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x; j < n4d; j += (int64_t)dense_blocks * 256) {
+      const int64_t i = j < sp.lo4 ? j : j + gap;
+      const float4 v = reinterpret_cast<const float4*>(g)[i];
+      acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+    }
+  } else {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int row = ((int)blockIdx.x - dense_blocks) * 4 + wave; row < sp.rows; row += SPARSE_ROW_BLOCKS * 4) {
+      if (!sp.touched[row]) continue;
+      for (int c = lane; c < sp.row_len4; c += 64) {
+        const float4 v = reinterpret_cast<const float4*>(g)[sp.lo4 + (int64_t)row * sp.row_len4 + c];
+        acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float t = g[(n4 << 2) + threadIdx.x]; acc += t * t; }
   acc = wave_sum(acc);
@@ -476,8 +494,9 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* partial, 
 struct AdamSegs { int64_t end[8]; float lr[8]; int n; };
 // dev_sched (may be NULL): [lr of segment 0..n-1, 1 - beta1^t, 1 - beta2^t] in DEVICE memory -- a captured (hipGraph) launch reads the
 // schedule of the current step from there instead of from its frozen by-value arguments
-__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, bf16_t* pb, int64_t n, AdamSegs segs, float b1, float b2,
-                                                   float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm, const float* dev_sched) {
+__global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, bf16_t* pb, int64_t n, AdamSegs segs, float b1, float b2,
+                                                   float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm, const float* dev_sched, SparseRows sp,
+                                                   int dense_blocks) {
   if (dev_sched) {
     for (int s = 0; s < segs.n; ++s) segs.lr[s] = dev_sched[s];
     bc1 = dev_sched[segs.n];
@@ -485,8 +504,22 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
   }
   float clip = 1.0f;
   if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));   // torch clip_grad_norm_
-  const int64_t n4 = n >> 2;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+  const int64_t n4 = n >> 2, gap = sp.hi4 - sp.lo4;
+  const bool row_block = (int)blockIdx.x >= dense_blocks;
+  // dense blocks: every float4 outside the row-sparse region; row blocks: the touched rows of that region, one wave per row -- whose gradient is
+  // cleared on the way out (the region is not zero-filled per step: untouched rows stay zero for ever)
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int row = row_block ? ((int)blockIdx.x - dense_blocks) * 4 + wave : 0, c = lane;
+  if (row_block) { while (row < sp.rows && !sp.touched[row]) row += SPARSE_ROW_BLOCKS * 4; }
+  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;; j += (int64_t)dense_blocks * 256) {
+    int64_t i;
+    if (!row_block) {
+      if (j >= n4 - gap) break;
+      i = j < sp.lo4 ? j : j + gap;
+    } else {
+      if (row >= sp.rows) break;
+      i = sp.lo4 + (int64_t)row * sp.row_len4 + c;
+    }
     const int64_t e0 = i << 2;
     float lr = 0.f;
 #pragma unroll
@@ -512,6 +545,15 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     __builtin_nontemporal_store((v4f){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<v4f*>(m) + i);
     __builtin_nontemporal_store((v4f){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<v4f*>(v) + i);
     if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3]));
+    if (row_block) {
+      reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      c += 64;
+      if (c >= sp.row_len4) {
+        c = lane;
+        row += SPARSE_ROW_BLOCKS * 4;
+        while (row < sp.rows && !sp.touched[row]) row += SPARSE_ROW_BLOCKS * 4;
+      }
+    }
   }
 }
 __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* y, int64_t n4) {
@@ -522,10 +564,12 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* x, bf16_t* 
 }
 
 // embedding backward: grad_table[idx[t], :] += dy[t, :]   (fp32 hardware atomics: rows may repeat)
-__global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg) {
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
+                                                            unsigned char* touched) {
   const int t = blockIdx.x;
   const int64_t row = idx[t];
   if (row < 0 || row >= rows || row == padding_idx) return;   // nn.Embedding(padding_idx=...) never accumulates into that row
+  if (touched && threadIdx.x == 0) touched[row] = 1;
   for (int c = threadIdx.x; c * 4 < D; c += 256) {
     float v[4];
     Ld4<bf16_t>::ld(dy, (int64_t)t * ldd + 4 * c, v);
@@ -537,10 +581,12 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, in
 
 // deterministic variant: idx sorted ascending; the block of the FIRST occurrence of a row walks all its duplicates in order and is the
 // only writer of that table row (data parallel: every rank scatters the same gathered list and must end with bit-identical gradients)
-__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg) {
+__global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
+                                                                   unsigned char* touched) {
   const int t = blockIdx.x;
   const int64_t row = idx[t];
   if (row < 0 || row >= rows || row == padding_idx || (t > 0 && idx[t - 1] == row)) return;
+  if (touched && threadIdx.x == 0) touched[row] = 1;
   int end = t + 1;
   while (end < T && idx[end] == row) ++end;
   for (int c = threadIdx.x; c * 4 < D; c += 256) {
@@ -695,36 +741,47 @@ extern "C" int sam_ptr_scores_bwd(const float* dscores, int64_t ld_b, int64_t ld
   return SAM_OK;
 }
 
-extern "C" int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, void* stream) {
+extern "C" int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg, uint8_t* touched,
+                                void* stream) {
   SAM_REQUIRE(dy && idx && grad, "sam_embedding_bwd: null pointer");
   SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && rows > 0, "sam_embedding_bwd: bad shape");
-  embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg);
+  embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg, touched);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
 
 extern "C" int sam_embedding_bwd_sorted(const void* dy, int64_t ldd, const int64_t* idx_sorted, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
-                                       void* stream) {
+                                       uint8_t* touched, void* stream) {
   SAM_REQUIRE(dy && idx_sorted && grad, "sam_embedding_bwd_sorted: null pointer");
   SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && ldg % 4 == 0 && rows > 0 && ((uintptr_t)grad % 16 == 0), "sam_embedding_bwd_sorted: bad shape");
-  embedding_bwd_sorted_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx_sorted, T, D, rows, padding_idx, grad, ldg);
+  embedding_bwd_sorted_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx_sorted, T, D, rows, padding_idx, grad, ldg, touched);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
 
-extern "C" int64_t sam_sumsq_ws_bytes(void) { return (int64_t)SUMSQ_BLOCKS * sizeof(float); }
-extern "C" int sam_sumsq_f32(const float* g, int64_t n, float* out, float* ws, void* stream) {
+static int fill_sparse(SparseRows& sp, const sam_sparse_rows* s, int64_t n) {
+  sp = SparseRows{0, 0, 1, 0, nullptr};
+  if (!s || !s->touched) return SAM_OK;
+  SAM_REQUIRE(s->row_len > 0 && s->row_len % 4 == 0 && s->lo % 4 == 0 && s->lo >= 0 && s->hi <= n && s->hi > s->lo && (s->hi - s->lo) % s->row_len == 0,
+              "row-sparse region: need 0 <= lo < hi <= n, lo and row_len multiples of 4, (hi - lo) a whole number of rows");
+  sp.lo4 = s->lo >> 2; sp.hi4 = s->hi >> 2; sp.row_len4 = s->row_len >> 2; sp.rows = (int)((s->hi - s->lo) / s->row_len); sp.touched = s->touched;
+  return SAM_OK;
+}
+extern "C" int64_t sam_sumsq_ws_bytes(void) { return (int64_t)(SUMSQ_BLOCKS + SPARSE_ROW_BLOCKS) * sizeof(float); }
+extern "C" int sam_sumsq_f32(const float* g, int64_t n, const sam_sparse_rows* sparse, float* out, float* ws, void* stream) {
   SAM_REQUIRE(g && out && ws && n > 0 && ((uintptr_t)g % 16 == 0), "sam_sumsq_f32: bad arguments");
+  SparseRows sp;
+  if (int rc = fill_sparse(sp, sparse, n)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const int blocks = (int)min((int64_t)SUMSQ_BLOCKS, ((n >> 2) + 255) / 256 + 1);
-  sumsq_partial_kernel<<<dim3(blocks), dim3(256), 0, st>>>(g, n, ws);
+  const int dense = (int)min((int64_t)SUMSQ_BLOCKS, ((n >> 2) + 255) / 256 + 1), blocks = dense + (sp.touched ? SPARSE_ROW_BLOCKS : 0);
+  sumsq_partial_kernel<<<dim3(blocks), dim3(256), 0, st>>>(g, n, sp, dense, ws);
   sumsq_final_kernel<<<dim3(1), dim3(256), 0, st>>>(ws, blocks, out);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
 
-static int adam_launch(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg, float beta1,
-                       float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const float* dev_sched, void* stream) {
+static int adam_launch(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg, float beta1,
+                       float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const float* dev_sched, const sam_sparse_rows* sparse, void* stream) {
   SAM_REQUIRE(p && g && m && v && seg_end && (seg_lr || dev_sched), "sam_adam_step: null pointer");
   SAM_REQUIRE(n > 0 && n % 4 == 0 && nseg >= 1 && nseg <= 8 && (step >= 1 || dev_sched), "sam_adam_step: need n %% 4 == 0, 1..8 segments, step >= 1");
   AdamSegs segs = {};
@@ -736,20 +793,22 @@ static int adam_launch(float* p, const float* g, float* m, float* v, void* p_bf1
   SAM_REQUIRE(seg_end[nseg - 1] == n, "sam_adam_step: last segment must end at n");
   const float bc1 = 1.0f - powf(beta1, (float)(step >= 1 ? step : 1));
   const float bc2 = 1.0f - powf(beta2, (float)(step >= 1 ? step : 1));
-  const int blocks = (int)min((int64_t)4096, ((n >> 2) + 255) / 256);
+  SparseRows sp;
+  if (int rc = fill_sparse(sp, sparse, n)) return rc;
+  const int dense = (int)min((int64_t)4096, ((n >> 2) + 255) / 256), blocks = dense + (sp.touched ? SPARSE_ROW_BLOCKS : 0);
   adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, segs, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), gnorm_sq, max_norm,
-                                                                   dev_sched);
+                                                                   dev_sched, sp, dense);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
-extern "C" int sam_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
-                             float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, void* stream) {
-  return adam_launch(p, g, m, v, p_bf16, n, seg_end, seg_lr, nseg, beta1, beta2, eps, step, gnorm_sq, max_norm, nullptr, stream);
+extern "C" int sam_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg,
+                             float beta1, float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream) {
+  return adam_launch(p, g, m, v, p_bf16, n, seg_end, seg_lr, nseg, beta1, beta2, eps, step, gnorm_sq, max_norm, nullptr, sparse, stream);
 }
-extern "C" int sam_adam_step_dev(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
-                                 float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, void* stream) {
+extern "C" int sam_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                                 float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream) {
   SAM_REQUIRE(dev_sched, "sam_adam_step_dev: null schedule");
-  return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, stream);
+  return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, sparse, stream);
 }
 
 // Head node of a captured (hipGraph) training step: everything that changes from replay to replay and used to be a by-value argument lives in

@@ -307,25 +307,37 @@ Tensor& workspace(const char* tag, int64_t bytes, const Tensor& like) {      // 
   if (!ws.defined() || ws.numel() * 4 < bytes) ws = at::empty({(bytes + 3) / 4}, like.options().dtype(at::kFloat));
   return ws;
 }
-void sumsq(const Tensor& g, Tensor out) {                                       // clip_grad_norm_'s norm, train.py:139
+// row-sparse region from its schema form: region = [lo, hi, row_len] (empty: none), touched = uint8 [rows]
+const sam_sparse_rows* sparse_of(sam_sparse_rows& s, at::IntArrayRef region, const optional<Tensor>& touched) {
+  if (region.size() != 3 || !touched.has_value() || !touched->defined()) return nullptr;
+  need(*touched, at::kByte, "touched");
+  s.lo = region[0]; s.hi = region[1]; s.row_len = (int32_t)region[2]; s.touched = (const uint8_t*)touched->data_ptr();
+  TORCH_CHECK(touched->numel() * region[2] >= region[1] - region[0], "row-sparse region: fewer flags than rows");
+  return &s;
+}
+void sumsq(const Tensor& g, Tensor out, at::IntArrayRef region, const optional<Tensor>& touched) {      // clip_grad_norm_'s norm, train.py:139
   need(g, at::kFloat, "g"); need(out, at::kFloat, "out");
   Tensor& ws = workspace("sumsq", sam_sumsq_ws_bytes(), g);
-  ok(sam_sumsq_f32((const float*)g.data_ptr(), g.numel(), (float*)out.data_ptr(), (float*)ws.data_ptr(), cur_stream()), "sam_sumsq_f32");
+  sam_sparse_rows s;
+  ok(sam_sumsq_f32((const float*)g.data_ptr(), g.numel(), sparse_of(s, region, touched), (float*)out.data_ptr(), (float*)ws.data_ptr(), cur_stream()), "sam_sumsq_f32");
 }
 // clip + Adam + bf16 shadow refresh over the flat buffers (train.py:139-142, task_utils.py:33-57).  dev_sched given: schedule read from device memory
 // (captured steps, see step_advance); else seg_lr / step by value.
-void adam_step(Tensor p_, const Tensor& g, Tensor m, Tensor v, const optional<Tensor>& p_bf16, at::IntArrayRef seg_end, at::ArrayRef<double> seg_lr, int64_t step,
-               double beta1, double beta2, double eps, const optional<Tensor>& gnorm_sq, double max_norm, const optional<Tensor>& dev_sched) {
+void adam_step(Tensor p_, Tensor g, Tensor m, Tensor v, const optional<Tensor>& p_bf16, at::IntArrayRef seg_end, at::ArrayRef<double> seg_lr, int64_t step,
+               double beta1, double beta2, double eps, const optional<Tensor>& gnorm_sq, double max_norm, const optional<Tensor>& dev_sched, at::IntArrayRef region,
+               const optional<Tensor>& touched) {
   need(p_, at::kFloat, "p"); need(g, at::kFloat, "g"); need(m, at::kFloat, "exp_avg"); need(v, at::kFloat, "exp_avg_sq");
   TORCH_CHECK(seg_end.size() >= 1 && seg_end.size() <= 8, "adam_step: 1..8 segments");
   int64_t ends[8]; float lrs[8] = {};
   for (size_t s = 0; s < seg_end.size(); ++s) { ends[s] = seg_end[s]; lrs[s] = s < seg_lr.size() ? (float)seg_lr[s] : 0.f; }
+  sam_sparse_rows s;
+  const sam_sparse_rows* sp = sparse_of(s, region, touched);
   if (dev_sched.has_value() && dev_sched->defined())
-    ok(sam_adam_step_dev((float*)p_.data_ptr(), (const float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, (int)seg_end.size(),
-                         (float)beta1, (float)beta2, (float)eps, (const float*)dev_sched->data_ptr(), (const float*)p(gnorm_sq), (float)max_norm, cur_stream()), "sam_adam_step_dev");
+    ok(sam_adam_step_dev((float*)p_.data_ptr(), (float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, (int)seg_end.size(),
+                         (float)beta1, (float)beta2, (float)eps, (const float*)dev_sched->data_ptr(), (const float*)p(gnorm_sq), (float)max_norm, sp, cur_stream()), "sam_adam_step_dev");
   else
-    ok(sam_adam_step((float*)p_.data_ptr(), (const float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, lrs, (int)seg_end.size(),
-                     (float)beta1, (float)beta2, (float)eps, step, (const float*)p(gnorm_sq), (float)max_norm, cur_stream()), "sam_adam_step");
+    ok(sam_adam_step((float*)p_.data_ptr(), (float*)g.data_ptr(), (float*)m.data_ptr(), (float*)v.data_ptr(), p(p_bf16), p_.numel(), ends, lrs, (int)seg_end.size(),
+                     (float)beta1, (float)beta2, (float)eps, step, (const float*)p(gnorm_sq), (float)max_norm, sp, cur_stream()), "sam_adam_step");
 }
 // head node of a captured training step (include/sam_hip.h: sam_step_advance)
 void step_advance(const optional<Tensor>& rng_state, int64_t offset_stride, Tensor step_counter, at::ArrayRef<double> base_lr, int64_t warmup_iters, double warmup_factor,
@@ -442,9 +454,9 @@ TORCH_LIBRARY(sam_hip, m) {
   m.def("ptr_scores(Tensor q, Tensor k, Tensor ocr_mask, float scale) -> Tensor");
   m.def("ptr_scores_bwd(Tensor dscores, Tensor q, Tensor k, float scale) -> (Tensor, Tensor)");
   m.def("bce_loss(Tensor fixed, Tensor ocr, Tensor targets, Tensor loss_mask, float grad_scale, Tensor? global_count) -> (Tensor, Tensor, Tensor)");
-  m.def("sumsq(Tensor g, Tensor(a!) out) -> ()");
-  m.def("adam_step(Tensor(a!) p, Tensor g, Tensor(b!) m, Tensor(c!) v, Tensor(d!)? p_bf16, int[] seg_end, float[] seg_lr, int step, float beta1, float beta2, float eps, "
-        "Tensor? gnorm_sq, float max_norm, Tensor? dev_sched) -> ()");
+  m.def("sumsq(Tensor g, Tensor(a!) out, int[] sparse_region, Tensor? touched) -> ()");
+  m.def("adam_step(Tensor(a!) p, Tensor(e!) g, Tensor(b!) m, Tensor(c!) v, Tensor(d!)? p_bf16, int[] seg_end, float[] seg_lr, int step, float beta1, float beta2, float eps, "
+        "Tensor? gnorm_sq, float max_norm, Tensor? dev_sched, int[] sparse_region, Tensor? touched) -> ()");
   m.def("step_advance(Tensor(a!)? rng_state, int offset_stride, Tensor(b!) step_counter, float[] base_lr, int warmup_iters, float warmup_factor, int[] decay_iters, "
         "float lr_decay, float beta1, float beta2, Tensor(c!) dev_sched) -> ()");
   m.def("encoder_layer_fwd(Tensor x, Tensor allow, Tensor[] params, int batch, int heads, float scale, float p_attn, float p_hid, int[] seeds, float eps1, "

@@ -469,41 +469,56 @@ def ptr_scores_bwd(dscores, q, k, scale):
     return dq, dk
 
 
-def sumsq(g, out):
+def _sparse_struct(sparse):
+    """sparse = (lo, hi, row_len, touched uint8 tensor) or None -> (ctypes pointer or None, keep-alive)"""
+    if sparse is None:
+        return None, None
+    import ctypes as C
+    s = capi.SparseRows()
+    s.lo, s.hi, s.row_len, s.touched = int(sparse[0]), int(sparse[1]), int(sparse[2]), sparse[3].data_ptr()
+    return C.cast(C.pointer(s), C.c_void_p), s
+
+
+def sumsq(g, out, sparse=None):
+    """out[0] = sum g^2; sparse = (lo, hi, row_len, touched): rows of that region whose flag is 0 are skipped (sam_sparse_rows)"""
     t_ = _tops()
     if t_ is not None:
-        t_.sumsq(g, out)
+        t_.sumsq(g, out, list(sparse[:3]) if sparse else [], sparse[3] if sparse else None)
         return out
     ws = _workspace(capi.call("sam_sumsq_ws_bytes"), g.device, "sumsq")
-    capi.call("sam_sumsq_f32", capi.ptr(g), g.numel(), capi.ptr(out), capi.ptr(ws), capi.stream_handle())
+    sp, keep = _sparse_struct(sparse)
+    capi.call("sam_sumsq_f32", capi.ptr(g), g.numel(), sp, capi.ptr(out), capi.ptr(ws), capi.stream_handle())
     return out
 
 
-def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
+def adam_step(p, g, m, v, p_bf16, seg_end, seg_lr, step, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8, sparse=None):
     t_ = _tops()
     if t_ is not None:
         t_.adam_step(p, g, m, v, p_bf16, [int(e) for e in seg_end], [float(l) for l in seg_lr], int(step), float(betas[0]), float(betas[1]), float(eps), gnorm_sq,
-                     float(max_norm), None)
+                     float(max_norm), None, list(sparse[:3]) if sparse else [], sparse[3] if sparse else None)
         return
     import ctypes as C
     n = len(seg_end)
     ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
     lrs = (C.c_float * n)(*[float(l) for l in seg_lr])
+    sp, keep = _sparse_struct(sparse)
     capi.call("sam_adam_step", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, lrs, n, float(betas[0]), float(betas[1]),
-              float(eps), int(step), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
+              float(eps), int(step), capi.ptr(gnorm_sq), float(max_norm), sp, capi.stream_handle())
 
 
-def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8):
+def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8, sparse=None):
     """adam_step with the schedule [lr per segment, 1 - beta1^t, 1 - beta2^t] read from the device tensor `dev_sched` (graph-captured steps)"""
     t_ = _tops()
     if t_ is not None:
-        t_.adam_step(p, g, m, v, p_bf16, [int(e) for e in seg_end], [], 0, float(betas[0]), float(betas[1]), float(eps), gnorm_sq, float(max_norm), dev_sched)
+        t_.adam_step(p, g, m, v, p_bf16, [int(e) for e in seg_end], [], 0, float(betas[0]), float(betas[1]), float(eps), gnorm_sq, float(max_norm), dev_sched,
+                     list(sparse[:3]) if sparse else [], sparse[3] if sparse else None)
         return
     import ctypes as C
     n = len(seg_end)
     ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
+    sp, keep = _sparse_struct(sparse)
     capi.call("sam_adam_step_dev", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, n, float(betas[0]), float(betas[1]),
-              float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), capi.stream_handle())
+              float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), sp, capi.stream_handle())
 
 
 def step_advance(rng_state, offset_stride, step_counter, base_lrs, dev_sched, betas=(0.9, 0.999), warmup_iters=1000, warmup_factor=0.2,
@@ -539,17 +554,18 @@ def cast_bf16(x, y):
 
 
 def embedding_bwd(dy, idx, grad_table, padding_idx=-1):
-    """grad_table[idx[t], :] += dy[t, :]  (dy bf16 [T,D], idx int64 [T], grad_table fp32 [rows, D]); padding_idx rows are skipped"""
+    """grad_table[idx[t], :] += dy[t, :]  (dy bf16 [T,D], idx int64 [T], grad_table fp32 [rows, D]); padding_idx rows are skipped.
+    grad_table._sam_touched (uint8 [rows], set by the Trainer): the rows that receive a gradient are flagged (row-sparse optimizer)"""
     t, d = dy.shape
     capi.call("sam_embedding_bwd", capi.ptr(dy), dy.stride(0), capi.ptr(idx), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table), grad_table.stride(0),
-              capi.stream_handle())
+              capi.ptr(getattr(grad_table, "_sam_touched", None)), capi.stream_handle())
 
 
 def embedding_bwd_sorted(dy, idx_sorted, grad_table, padding_idx=-1):
     """embedding_bwd for an index list sorted ascending: fixed summation order, one writer per table row (no atomics)"""
     t, d = dy.shape
     capi.call("sam_embedding_bwd_sorted", capi.ptr(dy), dy.stride(0), capi.ptr(idx_sorted), t, d, grad_table.shape[0], int(padding_idx), capi.ptr(grad_table),
-              grad_table.stride(0), capi.stream_handle())
+              grad_table.stride(0), capi.ptr(getattr(grad_table, "_sam_touched", None)), capi.stream_handle())
 
 
 def mask_bits_from_int8_bhnn(rel, base_bits=None):

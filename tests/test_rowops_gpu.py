@@ -157,6 +157,58 @@ def test_gradnorm_and_adam_match_torch():
         assert torch.equal(pb.cpu(), p.cpu().to(torch.bfloat16))
 
 
+@pytest.mark.parametrize("route", ["0", "1"])
+def test_row_sparse_region_is_bit_identical_to_the_dense_pass(route, monkeypatch):
+    """sam_sparse_rows: a table region whose untouched rows (g = m = v = 0) are skipped by the norm and by Adam gives the same norm and, bit for bit, the same
+    parameters / moments / bf16 shadows as the dense pass over several steps with changing touched sets; the touched rows' gradient is cleared by the
+    optimizer, the flags are set by the embedding backward; through ctypes and through torch.ops"""
+    monkeypatch.setenv("SAM_COARSE_OPS", route)
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(3)
+    rows, d, head, tail = 301, 768, 4096, 1000 * 4
+    lo, hi = head, head + rows * d
+    n = hi + tail
+    p0 = torch.randn(n, generator=g)
+    state = {}
+    for mode in ("dense", "sparse"):
+        p, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+        pb = p0.to(torch.bfloat16).cuda()                 # (the shadows exist before the first step: rows that are never updated keep them)
+        grad = torch.zeros(n).cuda()
+        table_g = grad[lo:hi].view(rows, d)
+        touched = torch.zeros(rows, dtype=torch.uint8).cuda()
+        if mode == "sparse":
+            table_g._sam_touched = touched
+        sp = (lo, hi, d, touched) if mode == "sparse" else None
+        nsq = torch.zeros(1).cuda()
+        gg = torch.Generator().manual_seed(4)
+        norms = []
+        for step in range(1, 5):
+            if mode == "dense":
+                grad[lo:hi].zero_()
+            grad[:lo] = torch.randn(lo, generator=gg).cuda() * 0.1
+            grad[hi:] = torch.randn(tail, generator=gg).cuda() * 0.1
+            ids = torch.randint(0, rows, (40,), generator=gg)
+            ids[:5] = 0                                                              # padding row: never receives a gradient
+            dy = torch.randn(40, d, generator=gg).to(torch.bfloat16).cuda()
+            order = torch.sort(ids, stable=True)
+            ops.embedding_bwd_sorted(dy[order.indices.cuda()].contiguous(), order.values.cuda(), table_g, padding_idx=0)
+            ops.sumsq(grad, nsq, sparse=sp)
+            norms.append(nsq.item())
+            if mode == "sparse":                 # the clip factor from the DENSE norm in both runs: the two norms differ in their last bits (another
+                nsq.fill_(state["dense"][4][step - 1])      # partition of the same addends), which would move every parameter by an ulp
+            ops.adam_step(p, grad, m, v, pb, [lo, n], [1e-3, 3e-4], step, gnorm_sq=nsq, max_norm=0.25, sparse=sp)
+            if mode == "sparse":
+                assert (table_g == 0).all()                                           # cleared row by row, no per-step fill
+                assert touched[0].item() == 0 and touched.sum().item() > 30
+        state[mode] = (p.cpu(), m.cpu(), v.cpu(), pb.cpu(), norms)
+    for a, b in zip(state["dense"][:4], state["sparse"][:4]):
+        assert torch.equal(a, b)
+    for a, b in zip(state["dense"][4], state["sparse"][4]):
+        assert abs(a - b) <= 1e-6 * abs(a)                                            # (same addends, another partition of the partial sums)
+    never = (state["sparse"][1][lo:hi].view(rows, d) == 0).all(1)
+    assert never.sum() > 100 and torch.equal(state["sparse"][0][lo:hi].view(rows, d)[never], p0[lo:hi].view(rows, d)[never])
+
+
 def test_sorted_embedding_backward_is_deterministic_and_equals_index_add():
     """sam_embedding_bwd_sorted (data-parallel row-sparse exchange): one writer per table row, duplicates summed in list order"""
     from sam_textvqa_amd import ops
