@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out
+bash tools/profile_bench.sh r3m --no-secondary
+cd $GRAFT_REPO_ROOT
+python tools/bench_wgrad.py 11648 > gpurun_out/r3m_micro_wgrad.txt 2>&1
+python tools/bench_wgrad.py 1280 >> gpurun_out/r3m_micro_wgrad.txt 2>&1
+python tools/bench_attn.py > gpurun_out/r3m_micro_attn.txt 2>&1
+python tools/bench_gemm8.py > gpurun_out/r3m_micro_gemm.txt 2>&1
+python tools/bench_adam.py > gpurun_out/r3m_micro_adam.txt 2>&1
+python bench.py > gpurun_out/r3m_bench.json 2> gpurun_out/r3m_bench.err
+tail -c 600 gpurun_out/r3m_bench.json
