@@ -293,6 +293,49 @@ int sam_greedy_pick(const float* fixed_scores, int64_t ld_fixed, const float* oc
 int sam_beam_step(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,
                   int32_t* ctl, float* cum, uint8_t* done, int64_t* seqs, int64_t* prev_pos, void* stream);
 
+/* ---- greedy decoding steps t_begin .. t_end-1 as ONE persistent launch (csrc/decode_steps.hip; sam/sa_m4c.py:285-302, rows of 294-302's loop) ----
+ * After a full first pass (step 0) every later step only has ONE new row per sample: decoder row t, whose input token was picked by step t-1 and
+ * which, under the prefix-LM mask (sa_m4c.py:834-844), sees the encoder rows and decoder rows 0..t -- so row t of the reference's last full forward
+ * is what step t computes here.  Per step and sample: PrevPredEmbeddings of prev_inds[b, t] (sa_m4c.py:928-948, eval mode), every encoder layer
+ * (QKV projection written into row n_enc + t of that layer's q|k|v cache, attention over cache rows 0..n_enc+t under the allow bits, output
+ * projection + LayerNorm, FFN + LayerNorm), classifier logits into fixed_scores[b, t, :V] and pointer scores into ocr_scores[b, t, :No]
+ * (sa_m4c.py:270-278, 866-897), prev_inds[b, t+1] = argmax over [logits | pointer scores] (first maximum wins).  The stages are phases of one
+ * kernel separated by grid barriers (one block per CU); all steps run inside the launch.
+ *   layers[l]: bf16 weights (wqkv = q|k|v stacked, [3D, D]) in the FRAGMENT-TILED layout [out / 16][in / 8][16][8] -- element (o, i) at
+ *     ((o / 16 * (in / 8) + i / 8) * 16 + o % 16) * 8 + i % 8, `out` zero-padded to a multiple of 16: what an MFMA operand load of 16 rows reads as
+ *     one contiguous kilobyte (row-major rows cost one tag lookup per lane: 6.5 us per phase) --, fp32 biases and LayerNorm vectors; qkv = that layer's
+ *     bf16 [B, N, 3D] row-major cache as left by the first pass (sam_gemm_bf16 of all rows); allow = the layer's bits [B, Hm, N, ceil(N/32)] with strides.
+ *   ans_ln bf16 [V, D], ocr_ln bf16 [B*No, D]: the two step-invariant LayerNorms of PrevPredEmbeddings; pos_emb / type_emb fp32 rows (ld in elements);
+ *   wc bf16 [V -> multiple of 16, D] and wq bf16 [D, D], both fragment-tiled as above; bc, bq fp32; ptr_k bf16 [B, No, D] the pointer network's keys; ocr_mask u8 [B, No]; ptr_scale = 1/sqrt(D);
+ *   prev_inds int64 [B, S]; fixed_scores fp32 [B, S, ld_fixed], ocr_scores fp32 [B, S, No]; seq_out (may be NULL) bf16 [B, N, D] receives the final
+ *     hidden state of row n_enc + t.
+ * Built for D = 768, F = 3072, head_dim 64, N <= 256, No <= 64, <= 8 layers: anything else returns SAM_ERR_UNSUPPORTED (callers fall back to the
+ * per-kernel step).  ws: sam_greedy_decode_ws_bytes(B, S, n_layers) bytes (~50 MB at B = 64: the activations of every (step, layer) get their own
+ * slot, see csrc/decode_steps.hip on coherence), 256-byte aligned; int32 word 32 of it (byte 128) is a sticky error flag, non-zero when
+ * a grid barrier timed out.  Zero the whole workspace once after allocation and again after an error: a clean launch leaves the barrier words at zero. */
+typedef struct sam_decode_layer {
+  const void *wqkv, *wo, *w1, *w2;
+  const float *bqkv, *bo, *b1, *b2, *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+  void* qkv;
+  const uint32_t* allow; int64_t allow_stride_b, allow_stride_h;
+} sam_decode_layer;
+typedef struct sam_decode_desc {
+  int32_t n_layers, B, N, n_enc, S, H, D, F, V, No, t_begin, t_end;
+  float scale, ln_eps, emb_ln_eps, ptr_scale;
+  const sam_decode_layer* layers;                       /* host array of n_layers entries */
+  const float *pos_emb, *type_emb, *emb_ln_g, *emb_ln_b; int64_t ld_pos, ld_type;
+  const void *ans_ln, *ocr_ln;
+  const void* wc; const float* bc;
+  const void* wq; const float* bq;
+  const void* ptr_k; const uint8_t* ocr_mask;
+  int64_t* prev_inds;
+  float* fixed_scores; int64_t ld_fixed;
+  float* ocr_scores;
+  void* seq_out;
+} sam_decode_desc;
+int64_t sam_greedy_decode_ws_bytes(int B, int S, int n_layers);
+int sam_greedy_decode_steps(const sam_decode_desc* desc, void* ws, int64_t ws_bytes, void* stream);
+
 /* ---- dropout RNG state in device memory (hipGraph capture) ----
  * Every dropout site takes (seed, offset) BY VALUE (counter-based: the backward regenerates the forward's mask from the same pair).  Launches
  * captured in a hipGraph would replay the same masks for ever; with a device-side state set, kernels launched afterwards (from any thread of

@@ -73,9 +73,11 @@ SIGNATURES = {
     "sam_attn_fwd_dec": [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "sam_greedy_pick": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
     "sam_beam_step": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
+    "sam_greedy_decode_ws_bytes": [_i, _i, _i],
+    "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes"}
-RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
+RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
 
 _lib = None
 
@@ -89,6 +91,21 @@ class LrSchedule(C.Structure):
     """mirror of `sam_lr_schedule` (include/sam_hip.h)"""
     _fields_ = [("base_lr", C.c_double * 8), ("nseg", C.c_int32), ("warmup_iters", _i64), ("warmup_factor", C.c_double), ("n_decay", C.c_int32),
                 ("decay_iters", _i64 * 4), ("lr_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double)]
+
+
+class DecodeLayer(C.Structure):
+    """mirror of `sam_decode_layer` (include/sam_hip.h)"""
+    _fields_ = [(n, _vp) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv", "allow")] + \
+               [("allow_stride_b", _i64), ("allow_stride_h", _i64)]
+
+
+class DecodeDesc(C.Structure):
+    """mirror of `sam_decode_desc` (include/sam_hip.h)"""
+    _fields_ = [(n, C.c_int32) for n in ("n_layers", "B", "N", "n_enc", "S", "H", "D", "F", "V", "No", "t_begin", "t_end")] + \
+               [(n, C.c_float) for n in ("scale", "ln_eps", "emb_ln_eps", "ptr_scale")] + \
+               [("layers", C.POINTER(DecodeLayer)), ("pos_emb", _vp), ("type_emb", _vp), ("emb_ln_g", _vp), ("emb_ln_b", _vp), ("ld_pos", _i64), ("ld_type", _i64),
+                ("ans_ln", _vp), ("ocr_ln", _vp), ("wc", _vp), ("bc", _vp), ("wq", _vp), ("bq", _vp), ("ptr_k", _vp), ("ocr_mask", _vp),
+                ("prev_inds", _vp), ("fixed_scores", _vp), ("ld_fixed", _i64), ("ocr_scores", _vp), ("seq_out", _vp)]
 
 
 class LnFinalizeItem(C.Structure):

@@ -10,7 +10,12 @@ eager PyTorch in between.  Here:
     PrevPredEmbeddings, the pointer network's keys, every mask);
   * the token selection is a kernel working in place on the decoder state (sam_greedy_pick / sam_beam_step), so a step needs no host decision;
   * the first pass and the decoding step are captured as two hipGraphs over static buffers: a batch costs one input copy, one replay of the
-    first graph and n_dec - 1 replays of the second (the eager loop was bound by ~70 launches x 12 steps of host time).
+    first graph and n_dec - 1 replays of the second (the eager loop was bound by ~70 launches x 12 steps of host time);
+  * greedy decoding goes one step further (sam_greedy_decode_steps, csrc/decode_steps.hip): step t only has ONE new row per sample -- decoder
+    row t, whose token step t-1 picked and which never changes afterwards -- so steps 1..n_dec-1 run as a single persistent kernel whose phases
+    (projection, attention over the cached keys / values, output projection + LayerNorm, FFN + LayerNorm, classifier, pointer scores, argmax,
+    next embedding) are separated by grid barriers instead of ~56 launches per step.  The per-kernel step stays for beam search (beams are
+    re-gathered between steps) and for model shapes the fused kernel is not built for (SAM_DECODE_FUSED=0 forces it).
 Beam search keeps the reference's structure -- every sample repeated beam_size times, candidates ranked over the flattened [beam, vocab] axis,
 surviving beams re-gathered -- and its exact arithmetic, including the quirks listed in oracle/beam_search.py (integer `indices / vocab_size`,
 cumulative scores that count the source beam twice, completed beams forced onto EOS); the re-gathering of the batch's feature tensors by
@@ -108,6 +113,10 @@ def graph_enabled():
     return os.environ.get("SAM_DECODE_GRAPH", "1") != "0"
 
 
+def fused_enabled():
+    return os.environ.get("SAM_DECODE_FUSED", "1") != "0"
+
+
 class DecodeSession:
     """static buffers + the two captured graphs for one (model, input shapes, beam size)"""
 
@@ -127,6 +136,7 @@ class DecodeSession:
         self.rows, self.steps = self.bd["train_prev_inds"].shape
         self.graph_first = self.graph_step = None
         self.pool = None
+        self.fused = None          # decided after the first pass: (layers, desc, workspace) of sam_greedy_decode_steps, or False
 
     # ---- what is enqueued ------------------------------------------------------------------------------------
     def _first(self):
@@ -179,6 +189,8 @@ class DecodeSession:
         self.ptr_k = ops.gemm(ocr_rows.view(r * self.n_ocr, d), wv, epilogue=capi.EPI_BIAS, bias=bv).view(r, self.n_ocr, -1)
         y_dec = self.seq[:, self.n - s:].reshape(r * s, d)
         self.out_first = self._head_and_pick(y_dec)
+        if self.fused is None or self.fused:
+            self.fused = self._fused_plan()         # (rebuilt on every _first: the capture's allocations replace the eager round's)
 
     def _dec_embed(self):
         """PrevPredEmbeddings.forward for the current train_prev_inds, eval mode (sa_m4c.py:928-948) -> bf16 [R*S, D]"""
@@ -202,6 +214,61 @@ class DecodeSession:
             x = _layer_tail(layer, ctx, x)
         self.y_dec = x
         self.out_step = self._head_and_pick(x)
+
+    def _fused_plan(self):
+        """arguments of sam_greedy_decode_steps over this session's static buffers (after _first), or False when the fused kernel does not apply.
+        Part of the first pass (captured with it): the weights are re-tiled into the MFMA fragment layout here, once per batch (~170 MB of copies,
+        ~1 % of a batch), so a session never decodes with the weights of an earlier training step."""
+        m, mmt = self.model, self.model.mmt
+        r, s = self.rows, self.steps
+        if self.beam or s < 2 or not fused_enabled():
+            return False
+        layers = []
+        eps = None
+        for (layer, bits), (qkv_full, _, _) in zip(self.plan, self.caches):
+            att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
+            wqkv, bqkv, _, _ = _fused_qkv(att)
+            d3, d = wqkv.shape
+            if d != 768 or inter.dense.weight.shape[0] != 3072 or att.attention_head_size != 64 or d3 != 3 * d:
+                return False
+            e1, e2 = float(so.LayerNorm.variance_epsilon), float(out.LayerNorm.variance_epsilon)
+            if eps is None:
+                eps = e1
+            if e1 != eps or e2 != eps:
+                return False
+            layers.append({"wqkv": ops.tile_weight(wqkv), "bqkv": bqkv, "wo": ops.tile_weight(_w(so.dense.weight)), "bo": so.dense.bias.data, "ln1_g": so.LayerNorm.weight.data, "ln1_b": so.LayerNorm.bias.data,
+                           "w1": ops.tile_weight(_w(inter.dense.weight)), "b1": inter.dense.bias.data, "w2": ops.tile_weight(_w(out.dense.weight)),
+                           "b2": out.dense.bias.data,
+                           "ln2_g": out.LayerNorm.weight.data, "ln2_b": out.LayerNorm.bias.data, "qkv": qkv_full, "allow": bits})
+        if not 1 <= len(layers) <= 8 or self.n > 256 or not 1 <= self.n_ocr <= 64:
+            return False
+        pp = mmt.prev_pred_embeddings
+        wc, _, bc, _, _, _ = _padded_views(m.classifier.weight, m.classifier.bias)
+        pq = m.ocr_ptr_net.query
+        wq, _, bq, _, _, _ = _padded_views(pq.weight, pq.bias)
+        if wq.shape != (768, 768) or m.classifier.bias is None or pq.bias is None:
+            return False
+        fixed, dyn = self.out_first
+        att0 = self.plan[0][0].attention.self
+        desc = {"n_layers": len(layers), "B": r, "N": self.n, "n_enc": self.n - s, "S": s, "H": att0.num_attention_heads, "D": 768, "F": 3072,
+                "V": m.classifier.weight.shape[0], "No": self.n_ocr, "scale": 1.0 / math.sqrt(att0.attention_head_size), "ln_eps": eps,
+                "emb_ln_eps": float(pp.emb_layer_norm.variance_epsilon), "ptr_scale": 1.0 / math.sqrt(m.ocr_ptr_net.query_key_size),
+                "pos_emb": pp.position_embeddings.weight.data, "type_emb": pp.token_type_embeddings.weight.data, "emb_ln_g": pp.emb_layer_norm.weight.data,
+                "emb_ln_b": pp.emb_layer_norm.bias.data, "ans_ln": self.ans_ln, "ocr_ln": self.ocr_ln, "wc": ops.tile_weight(wc), "bc": bc, "wq": ops.tile_weight(wq), "bq": bq, "ptr_k": self.ptr_k,
+                "ocr_mask": self.ocr_mask, "prev_inds": self.prev, "fixed_scores": fixed if fixed.is_contiguous() else None, "ld_fixed": fixed.stride(0),
+                "ocr_scores": dyn, "seq_out": self.seq}
+        if desc["fixed_scores"] is None:            # a column slice of the padded logits block: same memory, row stride ld_fixed
+            desc["fixed_scores"] = torch.as_strided(fixed, (fixed.shape[0] * fixed.stride(0),), (1,))
+        if getattr(self, "_fused_ws", None) is None:
+            self._fused_ws = ops.greedy_decode_ws(r, s, len(layers), self.prev.device)
+        return layers, desc, self._fused_ws
+
+    def _steps_fused(self):
+        """decoding steps 1 .. S-1, one launch (the score blocks, prev_inds and the final hidden states of out_first / seq are completed in place)"""
+        layers, desc, ws = self.fused
+        ops.greedy_decode_steps(layers, desc, ws, 1, self.steps)
+        self.out_step = self.out_first
+        self.y_dec = None
 
     def _head_and_pick(self, y_dec):
         """classifier + pointer network on the decoder rows (sa_m4c.py:270-278), then the token selection in place on the decoder state"""
@@ -241,15 +308,21 @@ class DecodeSession:
         if not graph_enabled():
             self._first()
             last = self.out_first
-            for _ in range(self.steps - 1):
-                self._step()
-                last = self.out_step
+            if self.fused:
+                self._steps_fused()
+            else:
+                for _ in range(self.steps - 1):
+                    self._step()
+                    last = self.out_step
         else:
             self.graph_first.replay()
             last = self.out_first
-            for _ in range(self.steps - 1):
+            for _ in range(1 if self.fused else self.steps - 1):
                 self.graph_step.replay()
                 last = self.out_step
+        if self.fused and int(self._fused_ws[32].item()) != 0:
+            self._fused_ws.zero_()
+            raise capi.SamHipError("sam_greedy_decode_steps: a grid barrier timed out (the launch did not have the device to itself?)")
         return self._results(batch_dict, last)
 
     def _capture(self):
@@ -260,7 +333,7 @@ class DecodeSession:
         with torch.cuda.stream(st):
             self._first()
             if self.steps > 1:
-                self._step()
+                self._steps_fused() if self.fused else self._step()
         cur.wait_stream(st)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
@@ -270,7 +343,7 @@ class DecodeSession:
         g2 = torch.cuda.CUDAGraph()
         if self.steps > 1:
             with torch.cuda.graph(g2, pool=self.pool, stream=st):
-                self._step()
+                self._steps_fused() if self.fused else self._step()
         self.graph_first, self.graph_step = g1, g2
 
     def _results(self, batch_dict, last):
@@ -282,7 +355,7 @@ class DecodeSession:
         batch_dict["train_prev_inds"] = self.prev.clone()
         batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"] = self.enc
         seq = self.seq.clone()
-        if self.steps > 1:
+        if self.steps > 1 and self.y_dec is not None:
             seq[:, self.n - s:] = self.y_dec.view(r, s, -1)
         batch_dict["mmt_seq_output"] = seq
         n_txt = batch_dict["question_mask"].size(-1)

@@ -521,6 +521,62 @@ def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_nor
               float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), sp, capi.stream_handle())
 
 
+def greedy_decode_ws(batch, steps, n_layers, device):
+    """zero-filled workspace of sam_greedy_decode_steps for `batch` rows (int32 word 32 = its sticky error flag)"""
+    nbytes = capi.call("sam_greedy_decode_ws_bytes", int(batch), int(steps), int(n_layers))
+    return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
+
+
+def tile_weight(w):
+    """bf16 [N, K] (any row stride) -> the fragment-tiled copy [ceil(N / 16), K / 8, 16, 8] sam_greedy_decode_steps reads (rows zero-padded to 16)"""
+    n, k = w.shape
+    if k % 8:
+        raise capi.SamHipError("tile_weight: K must be a multiple of 8")
+    npad = (n + 15) // 16 * 16
+    if npad != n:
+        w = torch.cat([w, w.new_zeros((npad - n, k))], dim=0)
+    return w.reshape(npad // 16, 16, k // 8, 8).permute(0, 2, 1, 3).contiguous()
+
+
+def greedy_decode_steps(layers, d, ws, t_begin, t_end):
+    """greedy decoding steps t_begin .. t_end-1 in one persistent launch (sam_greedy_decode_steps, include/sam_hip.h).
+    layers: per encoder layer a dict of tensors {wqkv, wo, w1, w2 (bf16, fragment-tiled: tile_weight), bqkv, bo, b1, b2, ln1_g, ln1_b, ln2_g, ln2_b (fp32), qkv (bf16 [B*N, 3D] cache),
+    allow (int32 bits [B, Hm, N, NW])}; d: dict with the scalar fields and tensors of sam_decode_desc.  Raises SamHipError(UNSUPPORTED) for shapes the
+    kernel is not built for."""
+    import ctypes as C
+    arr = (capi.DecodeLayer * len(layers))()
+    for e, l in zip(arr, layers):
+        for k in ("wqkv", "wo", "w1", "w2"):
+            _chk(l[k], BF16, k)
+            if l[k].dim() != 4 or l[k].shape[2:] != (16, 8):
+                raise capi.SamHipError("greedy_decode_steps: %s must be fragment-tiled (ops.tile_weight)" % k)
+        _chk(l["qkv"], BF16, "qkv")
+        for k in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "ln1_g", "ln1_b", "ln2_g", "ln2_b", "qkv", "allow"):
+            setattr(e, k, l[k].data_ptr())
+        al = l["allow"]
+        e.allow_stride_b, e.allow_stride_h = al.stride(0), (0 if al.shape[1] == 1 else al.stride(1))
+    desc = capi.DecodeDesc()
+    for k in ("n_layers", "B", "N", "n_enc", "S", "H", "D", "F", "V", "No"):
+        setattr(desc, k, int(d[k]))
+    desc.t_begin, desc.t_end = int(t_begin), int(t_end)
+    for k in ("scale", "ln_eps", "emb_ln_eps", "ptr_scale"):
+        setattr(desc, k, float(d[k]))
+    desc.layers = arr
+    for k in ("pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "bc", "bq", "fixed_scores", "ocr_scores"):
+        _chk(d[k], torch.float32, k)
+    for k in ("ans_ln", "ocr_ln", "wc", "wq", "ptr_k"):
+        _chk(d[k], BF16, k)
+    _chk(d["prev_inds"], torch.int64, "prev_inds"); _chk(d["ocr_mask"], torch.uint8, "ocr_mask")
+    for k in ("pos_emb", "type_emb", "emb_ln_g", "emb_ln_b", "ans_ln", "ocr_ln", "wc", "bc", "wq", "bq", "ptr_k", "ocr_mask", "prev_inds", "fixed_scores", "ocr_scores"):
+        setattr(desc, k, d[k].data_ptr())
+    desc.seq_out = d["seq_out"].data_ptr() if d.get("seq_out") is not None else None
+    for k in ("wc", "wq"):
+        if d[k].dim() != 4 or d[k].shape[2:] != (16, 8):
+            raise capi.SamHipError("greedy_decode_steps: %s must be fragment-tiled (ops.tile_weight)" % k)
+    desc.ld_pos, desc.ld_type, desc.ld_fixed = d["pos_emb"].stride(0), d["type_emb"].stride(0), int(d["ld_fixed"])
+    capi.call("sam_greedy_decode_steps", C.cast(C.pointer(desc), C.c_void_p), capi.ptr(ws), ws.numel() * ws.element_size(), capi.stream_handle())
+
+
 def step_advance(rng_state, offset_stride, step_counter, base_lrs, dev_sched, betas=(0.9, 0.999), warmup_iters=1000, warmup_factor=0.2,
                  lr_decay_iters=(14000, 19000), lr_decay=0.1):
     """head node of a captured training step (sam_step_advance): rng_state[1] += offset_stride; t = ++step_counter[0];
