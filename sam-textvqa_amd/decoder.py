@@ -320,9 +320,12 @@ class DecodeSession:
             for _ in range(1 if self.fused else self.steps - 1):
                 self.graph_step.replay()
                 last = self.out_step
-        if self.fused and int(self._fused_ws[32].item()) != 0:
-            self._fused_ws.zero_()
-            raise capi.SamHipError("sam_greedy_decode_steps: a grid barrier timed out (the launch did not have the device to itself?)")
+        if self.fused:
+            code = int(self._fused_ws[256].item())
+            if code != 0:
+                self._fused_ws.zero_()
+                raise capi.SamHipError("sam_greedy_decode_steps failed on the device: " + ("the device does not deal the launch to eight XCDs evenly" if code == 2 else
+                                       "a barrier timed out (the launch did not have the device to itself?)"))
         return self._results(batch_dict, last)
 
     def _capture(self):

@@ -522,7 +522,7 @@ def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_nor
 
 
 def greedy_decode_ws(batch, steps, n_layers, device):
-    """zero-filled workspace of sam_greedy_decode_steps for `batch` rows (int32 word 32 = its sticky error flag)"""
+    """zero-filled workspace of sam_greedy_decode_steps for `batch` rows (int32 word 256 = its sticky error flag)"""
     nbytes = capi.call("sam_greedy_decode_ws_bytes", int(batch), int(steps), int(n_layers))
     return torch.zeros((nbytes + 3) // 4, dtype=torch.int32, device=device)
 

@@ -15,7 +15,7 @@ for _ in range(3):
         model(bd)
 torch.cuda.synchronize()
 ses = next(iter(model._sam_decode_sessions.values()))
-st = ses._fused_ws[64:64 + 2048].view(torch.int64).cpu().tolist()
+st = ses._fused_ws[288:288 + 2048].view(torch.int64).cpu().tolist()
 n_layers = 6
 names = ["E0"] + (["Q", "A", "O", "F1", "G", "H", "F2"] * n_layers + ["C", "P"]) * 11
 ts = [st[k] for k in range(1, len(names) + 1)]
@@ -27,6 +27,3 @@ for n, v in agg.items():
     print("%-3s n=%3d mean %.2f us  min %.2f max %.2f" % (n, len(v), sum(v) / len(v), min(v), max(v)))
 step = 7 * n_layers + 2
 print("per step us:", [round((ts[step * (i + 1)] - ts[step * i]) / 100.0, 1) for i in range(11)])
-st2 = ses._fused_ws[64 + 2000:64 + 2000 + 16].view(torch.int64).cpu().tolist()
-print("Q phase (step 2, layer 1) block 0: start->tile done %.2f us; prev-phase vmcnt %.2f..sync %.2f (stale slots); this-phase: stores drained at +%.2f, block synced +%.2f, barrier passed +%.2f"
-      % ((st2[1] - st2[0]) / 100, 0, 0, (st2[4] - st2[0]) / 100, (st2[5] - st2[0]) / 100, (st2[6] - st2[0]) / 100))
