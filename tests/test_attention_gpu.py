@@ -369,4 +369,4 @@ def test_dropout_streams_are_independent_across_rows_columns_offsets_and_seeds()
     z = ops.gemm(ones, eye, epilogue=capi.EPI_BIAS_DROPOUT_RES, p_drop=p, seed=3, offset=9)
     assert torch.equal((z != 0).float(), h0)
     # attention dropout and hidden dropout under the SAME (seed, offset) are different streams
-    assert abs(_agree(keep(3, 9)[0, 0, :, :182].reshape(-1)[: 182 * 182], h0[:182, :182].reshape(-1)) - indep) < 0.01
+    assert abs(_agree(keep(3, 9)[0, 0, :, :182].reshape(-1)[: 182 * 182].cpu(), h0[:182, :182].reshape(-1).cpu()) - indep) < 0.01
