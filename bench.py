@@ -333,6 +333,10 @@ def eval_decode(context, layers, vocab, shape, batch_size, dev, reps=6, warmup=3
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / reps
             out[name] = dict(ms_per_batch=round(1e3 * dt, 2), samples_per_s=round(batch_size / dt, 1))
+            if name == "greedy":
+                ses = [v for v in getattr(model, "_sam_decode_sessions", {}).values() if v.beam == 0]
+                out[name]["steps_path"] = ("one persistent kernel for steps 1..S-1 (sam_greedy_decode_steps)" if ses and ses[0].fused
+                                           else "captured per-kernel step") + ", first pass + steps as hipGraphs"
     del model
     torch.cuda.empty_cache()
     return dict(batch=batch_size, decoding_steps=shape[3], **out)

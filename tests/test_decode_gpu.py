@@ -221,6 +221,37 @@ def test_greedy_full_size_b64_session_equals_full_recompute(monkeypatch):
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("batch", [1, 5, 9, 17, 23])
+def test_persistent_decoding_kernel_at_ragged_batch_sizes(batch, monkeypatch):
+    """the XCD partition of sam_greedy_decode_steps at batch sizes that do not fill the eight groups evenly (1: one sample on one XCD; 9: 2+2+2+2+1,
+    three XCDs idle; 17: 3 x 5 + 2; 23: 3 x 7 + 2) against the per-kernel decoding step on the same batch: same tokens, scores and decoder rows within
+    the bf16 resolution; the error flag stays clear and the barrier words are back at zero after every launch"""
+    model, _, shapes = _models()
+    model.decode_cache = True
+    outs = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("SAM_DECODE_FUSED", fused)
+        monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
+        model.__dict__.pop("_sam_decode_sessions", None)
+        res = []
+        for seed in (31, 32):
+            bd = _batch(batch, shapes, 300, seed, "cuda")
+            with torch.no_grad():
+                sc = model(bd)["textvqa_scores"]
+            res.append((sc.float().cpu(), bd["train_prev_inds"].cpu(), bd["mmt_dec_output"].float().cpu()))
+        outs[fused] = res
+        ses = next(iter(model._sam_decode_sessions.values()))
+        assert bool(ses.fused) == (fused == "1")
+        if ses.fused:
+            ws = ses._fused_ws.cpu()
+            assert int(ws[256]) == 0 and all(int(ws[g * 32 + w]) == 0 for g in range(8) for w in range(3))
+    for a, b in zip(outs["0"], outs["1"]):
+        live = a[0] > -9000
+        err = ((a[0] - b[0]).abs()[live].max() / a[0][live].abs().max()).item()
+        herr = ((a[2] - b[2]).abs().max() / a[2].abs().max()).item()
+        assert torch.equal(a[1], b[1]) and err < 6e-3 and herr < 4e-2, (batch, err, herr)
+
+
 def test_greedy_decode_steps_rejects_what_it_is_not_built_for():
     from sam_textvqa_amd import ops
     from sam_textvqa_amd._capi import SamHipError
