@@ -336,6 +336,21 @@ typedef struct sam_decode_desc {
 int64_t sam_greedy_decode_ws_bytes(int B, int S, int n_layers);
 int sam_greedy_decode_steps(const sam_decode_desc* desc, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- glue (csrc/glue.hip): up to 8 strided block copies / casts / accumulations / zero-fills in ONE launch ----
+ * block q: dst[b, i, :cols] (+)= src[b, i, :cols] for b < batches, i < rows; element (b, i, c) at b * batch_stride + i * row_stride + c; src NULL = zeros;
+ * src_f32 / dst_f32: 1 = fp32, 0 = bf16 (converted with round-to-nearest-even); accumulate: dst += src.  cols and every stride multiples of 4 elements.
+ * Replaces torch.cat of the four token groups (sam/sa_m4c.py:814-818) and its backward's four slice copies, the OCR / decoder row slices of the MMT
+ * output (sa_m4c.py:270-278) with their zero-padded gradient, the casts and zero-fills around PrevPredEmbeddings' backward (sa_m4c.py:900-948), the
+ * clearing of the accumulated gradient ranges.  sam_ge_u8: out[i] = x[i] >= threshold (token type of a previous prediction, sa_m4c.py:936). */
+typedef struct sam_copy_desc {
+  const void* src; void* dst;
+  int32_t batches, rows, cols;
+  int64_t src_batch_stride, src_row_stride, dst_batch_stride, dst_row_stride;
+  int32_t src_f32, dst_f32, accumulate;
+} sam_copy_desc;
+int sam_copy_blocks(const sam_copy_desc* descs, int count, void* stream);
+int sam_ge_u8(const int64_t* x, int64_t n, int64_t threshold, uint8_t* out, void* stream);
+
 /* ---- dropout RNG state in device memory (hipGraph capture) ----
  * Every dropout site takes (seed, offset) BY VALUE (counter-based: the backward regenerates the forward's mask from the same pair).  Launches
  * captured in a hipGraph would replay the same masks for ever; with a device-side state set, kernels launched afterwards (from any thread of

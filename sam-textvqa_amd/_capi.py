@@ -74,6 +74,8 @@ SIGNATURES = {
     "sam_greedy_pick": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
     "sam_beam_step": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sam_greedy_decode_ws_bytes": [_i, _i, _i],
+    "sam_copy_blocks": [C.c_void_p, _i, _vp],
+    "sam_ge_u8": [_vp, _i64, _i64, _vp, _vp],
     "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
 }
 NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
@@ -91,6 +93,12 @@ class LrSchedule(C.Structure):
     """mirror of `sam_lr_schedule` (include/sam_hip.h)"""
     _fields_ = [("base_lr", C.c_double * 8), ("nseg", C.c_int32), ("warmup_iters", _i64), ("warmup_factor", C.c_double), ("n_decay", C.c_int32),
                 ("decay_iters", _i64 * 4), ("lr_decay", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double)]
+
+
+class CopyDesc(C.Structure):
+    """mirror of `sam_copy_desc` (include/sam_hip.h)"""
+    _fields_ = [("src", _vp), ("dst", _vp), ("batches", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("src_batch_stride", _i64), ("src_row_stride", _i64),
+                ("dst_batch_stride", _i64), ("dst_row_stride", _i64), ("src_f32", C.c_int32), ("dst_f32", C.c_int32), ("accumulate", C.c_int32)]
 
 
 class DecodeLayer(C.Structure):

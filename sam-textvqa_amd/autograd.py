@@ -224,7 +224,7 @@ class PrevPredFn(Function):
             ocr_x = ocr_x.contiguous()
         ocr, m_o, r_o = ops.layernorm_fwd(ocr_x, mod.ocr_layer_norm.weight, mod.ocr_layer_norm.bias, mod.ocr_layer_norm.variance_epsilon)
         inds = prev_inds.contiguous()
-        is_ocr = inds.ge(ans_emb.shape[0]).view(torch.uint8).reshape(-1)         # token type 1 for copied OCR tokens, sa_m4c.py:936
+        is_ocr = ops.ge_u8(inds, ans_emb.shape[0])                               # token type 1 for copied OCR tokens, sa_m4c.py:936
         e = ops.embed_sum_fwd(mod.position_embeddings.weight.data, mod.token_type_embeddings.weight.data, b * s, s, type_ids=is_ocr)
         emb, m_e, r_e = ops.layernorm_fwd(e, mod.emb_layer_norm.weight, mod.emb_layer_norm.bias, mod.emb_layer_norm.variance_epsilon)
         ctx.seed = dropout_clock.next()
@@ -246,14 +246,21 @@ class PrevPredFn(Function):
         d_e, _ = ops.layernorm_bwd(d_emb, e, m_e, r_e, ln.weight, ln.weight.grad, ln.bias.grad)
         tt = mod.token_type_embeddings.weight
         ops.embed_sum_bwd(d_e, inds.shape[1], mod.position_embeddings.weight.grad, tt.grad, is_ocr, n_types=min(4, tt.shape[0]))
+        d_ans16 = torch.empty(d_ans.shape, dtype=BF16, device=d_ans.device)
+        d_ocr16 = torch.empty(d_ocr.shape, dtype=BF16, device=d_ocr.device)
+        ops.copy_blocks([(d_ans.unsqueeze(0), d_ans16.unsqueeze(0)), (d_ocr.unsqueeze(0), d_ocr16.unsqueeze(0))])      # both fp32 -> bf16 casts: one launch
         ln = mod.ans_layer_norm
-        dx_ans, _ = ops.layernorm_bwd(d_ans.to(BF16), ans_x, m_a, r_a, ln.weight, ln.weight.grad, ln.bias.grad)
+        dx_ans, _ = ops.layernorm_bwd(d_ans16, ans_x, m_a, r_a, ln.weight, ln.weight.grad, ln.bias.grad)
         ln = mod.ocr_layer_norm
-        dx_ocr, _ = ops.layernorm_bwd(d_ocr.to(BF16), ocr_x, m_o, r_o, ln.weight, ln.weight.grad, ln.bias.grad)
+        dx_ocr, _ = ops.layernorm_bwd(d_ocr16, ocr_x, m_o, r_o, ln.weight, ln.weight.grad, ln.bias.grad)
         g_ans = None
         if getattr(ans_param, "_sam_flat", None) is not None and ans_param.grad is not None:
-            ans_param.grad.add_(dx_ans.float())               # prepared parameter (the classifier weight): accumulate here, not through autograd
-                                                              # (cast first: torch's mixed bf16 -> fp32 in-place add runs at a quarter of the speed)
+            # prepared parameter (the classifier weight): accumulate here, not through autograd -- bf16 rows added into the fp32 gradient in one launch
+            g = ans_param.grad
+            if g.dim() == 2 and g.stride(1) == 1 and g.stride(0) % 4 == 0 and g.shape[1] % 4 == 0:
+                ops.copy_blocks([(dx_ans.unsqueeze(0), g.unsqueeze(0), True)])
+            else:
+                g.add_(dx_ans.float())
         elif ctx.needs_input_grad[1]:
             g_ans = dx_ans.to(ans_param.dtype)
         g_ocr = dx_ocr.view(ocr_shape).to(ocr_dtype) if ctx.needs_input_grad[2] else None
@@ -268,17 +275,73 @@ class SeqRowsFn(Function):
     @staticmethod
     def forward(ctx, seq, ocr0, n_ocr, n_dec):
         ctx.cfg = (seq.shape, seq.dtype, ocr0, n_ocr, n_dec)
-        return seq[:, ocr0: ocr0 + n_ocr].contiguous(), seq[:, seq.shape[1] - n_dec:].contiguous()
+        a, b = seq[:, ocr0: ocr0 + n_ocr], seq[:, seq.shape[1] - n_dec:]
+        if _glue_ok(seq):
+            oa, ob = torch.empty(a.shape, dtype=seq.dtype, device=seq.device), torch.empty(b.shape, dtype=seq.dtype, device=seq.device)
+            ops.copy_blocks([(a, oa), (b, ob)])                 # one launch
+            return oa, ob
+        return a.contiguous(), b.contiguous()
 
     @staticmethod
     def backward(ctx, d_ocr, d_dec):
         shape, dtype, ocr0, n_ocr, n_dec = ctx.cfg
-        d = torch.zeros(shape, dtype=dtype, device=d_ocr.device if d_ocr is not None else d_dec.device)
+        ref = d_ocr if d_ocr is not None else d_dec
+        if d_ocr is not None and d_dec is not None and ocr0 + n_ocr + n_dec == shape[1] and _glue_ok(d_ocr) and _glue_ok(d_dec) and dtype in (BF16, torch.float32):
+            d = torch.empty(shape, dtype=dtype, device=ref.device)
+            blocks = [(d_ocr, d[:, ocr0: ocr0 + n_ocr]), (d_dec, d[:, shape[1] - n_dec:])]
+            if ocr0:
+                blocks.append((None, d[:, :ocr0]))
+            ops.copy_blocks(blocks)                             # zero rows + both slices: one launch
+            return d, None, None, None
+        d = torch.zeros(shape, dtype=dtype, device=ref.device)
         if d_ocr is not None:
             d[:, ocr0: ocr0 + n_ocr] = d_ocr
         if d_dec is not None:
             d[:, shape[1] - n_dec:] = d_dec
         return d, None, None, None
+
+
+def _glue_ok(t):
+    """can sam_copy_blocks address this [B, rows, cols] tensor?"""
+    return (t is not None and t.is_cuda and t.dim() == 3 and t.dtype in (BF16, torch.float32) and t.stride(2) == 1 and t.shape[2] % 4 == 0 and
+            t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 and t.data_ptr() % 16 == 0)
+
+
+class CatRowsFn(Function):
+    """torch.cat of token groups along dim 1 into the [B, N, D] bf16 sequence the MMT consumes (sam/sa_m4c.py:814-818): one launch forward; the backward
+    hands every group its contiguous gradient slice from ONE launch (autograd's cat backward returns strided views, which every consumer then copies)"""
+
+    @staticmethod
+    def forward(ctx, *groups):
+        b, d = groups[0].shape[0], groups[0].shape[2]
+        ctx.rows, ctx.dtypes = [g.shape[1] for g in groups], [g.dtype for g in groups]
+        out = torch.empty((b, sum(ctx.rows), d), dtype=BF16, device=groups[0].device)
+        blocks, r0 = [], 0
+        for g in groups:
+            blocks.append((g, out[:, r0: r0 + g.shape[1]]))
+            r0 += g.shape[1]
+        ops.copy_blocks(blocks)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        if not _glue_ok(dx):
+            dx = dx.contiguous()
+        outs, blocks, r0 = [], [], 0
+        for n, dt in zip(ctx.rows, ctx.dtypes):
+            o = torch.empty((dx.shape[0], n, dx.shape[2]), dtype=dt, device=dx.device)
+            blocks.append((dx[:, r0: r0 + n], o))
+            outs.append(o)
+            r0 += n
+        ops.copy_blocks(blocks)
+        return tuple(outs)
+
+
+def cat_rows(groups):
+    """the [B, N, D] bf16 concatenation of the token groups; CatRowsFn when every group is addressable by the block-copy kernel, torch.cat otherwise"""
+    if all(_glue_ok(g) for g in groups) and len(groups) <= 8 and len({(g.shape[0], g.shape[2]) for g in groups}) == 1:
+        return CatRowsFn.apply(*groups)
+    return torch.cat([g.to(BF16) for g in groups], dim=1)
 
 
 class DropoutFn(Function):

@@ -17,7 +17,8 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm, linear)
+from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, cat_rows, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm,
+                       linear)
 from .params import prepare
 from .registry import registry
 
@@ -501,8 +502,7 @@ class MMT(_HipModule):
         if ev is not None:                                # TextBert ran on a side stream (SAM4C.forward): join it here, as late as possible
             torch.cuda.current_stream().wait_event(ev)
             batch_dict["text_bert_emb"].record_stream(torch.cuda.current_stream())
-        x = torch.cat([batch_dict["text_bert_emb"].to(BF16), batch_dict["obj_mmt_in"].to(BF16), batch_dict["ocr_mmt_in"].to(BF16),
-                       dec_emb.to(BF16)], dim=1)
+        x = cat_rows([batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"], dec_emb])
         n_txt = batch_dict["question_mask"].size(-1)
         n_obj = batch_dict["pad_obj_mask"].size(-1)
         n_ocr = batch_dict["pad_ocr_mask"].size(-1)

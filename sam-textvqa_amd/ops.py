@@ -419,8 +419,9 @@ def gather2_add_bwd(dy, inds, v, n_ocr, want_emb=True, p_drop=0.0, seed=0, offse
     _chk(dy, BF16, "dy")
     b, s = inds.shape
     d = dy.shape[1]
-    d_ans = torch.zeros((v, d), dtype=torch.float32, device=dy.device)
-    d_ocr = torch.zeros((b * n_ocr, d), dtype=torch.float32, device=dy.device)
+    d_ans = torch.empty((v, d), dtype=torch.float32, device=dy.device)
+    d_ocr = torch.empty((b * n_ocr, d), dtype=torch.float32, device=dy.device)
+    copy_blocks([(None, d_ans.view(1, 1, -1)), (None, d_ocr.view(1, 1, -1))])       # both atomics buffers cleared by one launch
     d_emb = torch.empty((b * s, d), dtype=BF16, device=dy.device) if want_emb else None
     capi.call("sam_gather2_add_bwd", capi.ptr(dy), dy.stride(0), int(v), int(n_ocr), capi.ptr(inds), b, s, d, capi.ptr(d_ans), d_ans.stride(0), capi.ptr(d_ocr),
               d_ocr.stride(0), float(p_drop), int(seed), int(offset), capi.ptr(d_emb), d_emb.stride(0) if want_emb else 0, capi.stream_handle())
@@ -519,6 +520,36 @@ def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_nor
     sp, keep = _sparse_struct(sparse)
     capi.call("sam_adam_step_dev", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, n, float(betas[0]), float(betas[1]),
               float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), sp, capi.stream_handle())
+
+
+def copy_blocks(blocks):
+    """up to 8 strided copies / casts / accumulations / zero-fills in one launch (sam_copy_blocks).  Each block: (src | None, dst, accumulate=False) with
+    src / dst 3-D views [batches, rows, cols] (any batch / row stride, unit column stride, bf16 or fp32); src None fills dst with zeros."""
+    import ctypes as C
+    for i in range(0, len(blocks), 8):
+        part = blocks[i: i + 8]
+        arr = (capi.CopyDesc * len(part))()
+        for e, blk in zip(arr, part):
+            src, dst = blk[0], blk[1]
+            acc = bool(blk[2]) if len(blk) > 2 else False
+            if dst.dim() != 3 or dst.stride(2) != 1 or dst.dtype not in (BF16, torch.float32) or not dst.is_cuda:
+                raise capi.SamHipError("copy_blocks: dst must be a 3-D bf16 / fp32 GPU view with unit column stride")
+            if src is not None and (src.shape != dst.shape or src.stride(2) != 1 or src.dtype not in (BF16, torch.float32) or not src.is_cuda):
+                raise capi.SamHipError("copy_blocks: src must match dst's shape, bf16 / fp32, unit column stride")
+            e.src, e.dst = (src.data_ptr() if src is not None else None), dst.data_ptr()
+            e.batches, e.rows, e.cols = dst.shape
+            e.src_batch_stride, e.src_row_stride = (src.stride(0), src.stride(1)) if src is not None else (0, 0)
+            e.dst_batch_stride, e.dst_row_stride = dst.stride(0), dst.stride(1)
+            e.src_f32, e.dst_f32, e.accumulate = int(src is not None and src.dtype == torch.float32), int(dst.dtype == torch.float32), int(acc)
+        capi.call("sam_copy_blocks", C.cast(arr, C.c_void_p), len(part), capi.stream_handle())
+
+
+def ge_u8(x, threshold):
+    """uint8 [n] = x >= threshold for an int64 tensor (token types of the previous predictions, sa_m4c.py:936)"""
+    _chk(x, torch.int64, "x")
+    out = torch.empty(x.numel(), dtype=torch.uint8, device=x.device)
+    capi.call("sam_ge_u8", capi.ptr(x), x.numel(), int(threshold), capi.ptr(out), capi.stream_handle())
+    return out
 
 
 def greedy_decode_ws(batch, steps, n_layers, device):

@@ -119,13 +119,19 @@ class FlatParams:
         if not skip:
             self.grad.zero_()
             return
-        pos = 0
+        pos, pieces = 0, []
         for lo, hi in skip:
             if lo > pos:
-                self.grad[pos:lo].zero_()
+                pieces.append((pos, lo))
             pos = max(pos, hi)
         if pos < self.numel:
-            self.grad[pos:].zero_()
+            pieces.append((pos, self.numel))
+        if self.grad.is_cuda and pieces and all(a % 4 == 0 and (b - a) % 4 == 0 for a, b in pieces):
+            from . import ops
+            ops.copy_blocks([(None, self.grad[a:b].view(1, 1, b - a)) for a, b in pieces])      # every range in one launch
+        else:
+            for a, b in pieces:
+                self.grad[a:b].zero_()
 
     def range_of(self, module):
         """[start, end) element range of the flat buffers covering `module`'s parameters (they are contiguous)"""

@@ -72,6 +72,7 @@ class Trainer:
                     merged.append((lo, hi))
             self._fresh_ranges = merged
         self.defer_ln = os.environ.get("SAM_LN_DEFER_FINALIZE", "1") != "0"
+        self._grad_one = None
         self.sparse = self._setup_sparse_table() if os.environ.get("SAM_SPARSE_ADAM", "1") != "0" else None
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
@@ -278,7 +279,9 @@ class Trainer:
         if defer_ln:
             self._set_ln_defer(True)
         try:
-            loss.backward()
+            if self._grad_one is None or self._grad_one.device != loss.device:
+                self._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
+            loss.backward(self._grad_one)                       # (a resident 1.0: autograd would fill a fresh one every step)
         except BaseException:
             # whatever the LayerNorm backwards queued points into workspaces of a backward pass that no longer exists (under capture: into the
             # graph's private pool): drop it, or the next step's flush would reduce stale partial sums into dgamma / dbeta / dbias

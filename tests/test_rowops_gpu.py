@@ -337,3 +337,32 @@ def test_input_encoder_node_matches_fp32_reference(p_drop):
     y2.backward(gout)
     assert torch.equal(y2, y)
     close(enc.lb.weight.grad, 2 * before, "accumulated d W_b", 1e-5)
+
+
+def test_copy_blocks_and_ge_u8():
+    """sam_copy_blocks: strided slices, casts both ways, accumulation, zero-fill, several blocks per launch -- against torch"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(3)
+    seq = torch.randn(5, 182, 768, device="cuda", generator=g).bfloat16()
+    a, b = torch.empty(5, 50, 768, device="cuda", dtype=torch.bfloat16), torch.empty(5, 12, 768, device="cuda", dtype=torch.float32)
+    z = torch.full((5, 20, 768), 7.0, device="cuda", dtype=torch.bfloat16)
+    ops.copy_blocks([(seq[:, 120:170], a), (seq[:, 170:], b), (None, z)])
+    assert torch.equal(a, seq[:, 120:170]) and torch.equal(b, seq[:, 170:].float()) and not z.any()
+    out = torch.zeros(5, 182, 768, device="cuda", dtype=torch.bfloat16)
+    ops.copy_blocks([(a, out[:, 120:170]), (b, out[:, 170:])])                      # fp32 -> bf16 into a strided destination
+    assert torch.equal(out[:, 120:], seq[:, 120:]) and not out[:, :120].any()
+    acc = torch.randn(1, 300, 768, device="cuda", generator=g)
+    add = torch.randn(1, 300, 768, device="cuda", generator=g).bfloat16()
+    want = acc + add.float()
+    wide = torch.zeros(1, 300, 776, device="cuda")                                   # padded row stride, as the classifier's gradient view
+    wide[:, :, :768] = acc
+    ops.copy_blocks([(add, wide[:, :, :768], True)])
+    assert torch.equal(wide[:, :, :768], want) and not wide[:, :, 768:].any()
+    many = [torch.randn(2, 3, 8, device="cuda", generator=g) for _ in range(11)]     # more than 8 blocks: split over launches
+    outs = [torch.empty(2, 3, 8, device="cuda", dtype=torch.bfloat16) for _ in many]
+    ops.copy_blocks(list(zip(many, outs)))
+    assert all(torch.equal(o, m.bfloat16()) for o, m in zip(outs, many))
+    with pytest.raises(Exception):
+        ops.copy_blocks([(seq[:, :, :6], torch.empty(5, 182, 6, device="cuda", dtype=torch.bfloat16))])      # width not a multiple of 4
+    ids = torch.randint(0, 5050, (64, 12), device="cuda", generator=g)
+    assert torch.equal(ops.ge_u8(ids, 5000), ids.ge(5000).view(torch.uint8).reshape(-1))
