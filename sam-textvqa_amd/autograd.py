@@ -80,8 +80,8 @@ class LinearFn(Function):
     Any in_features / out_features: both are zero-padded to multiples of 8 (in storage for the weights, on the fly for x / dy)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, out_f32):
-        ctx.weight, ctx.bias = weight, bias
+    def forward(ctx, x, weight, bias, out_f32, side=None):
+        ctx.weight, ctx.bias, ctx.side = weight, bias, side
         wv, _, bv, _, n_pad, k_pad = _padded_views(weight, bias)
         n, k = weight.shape
         x2 = x.reshape(-1, x.shape[-1])
@@ -103,6 +103,8 @@ class LinearFn(Function):
         weight, bias = ctx.weight, ctx.bias
         wv, gv, _, dbv, n_pad, k_pad = _padded_views(weight, bias)
         n, k = weight.shape
+        if ctx.side is not None and "dy_bf16" in ctx.side:
+            dy = ctx.side.pop("dy_bf16")                         # the loss handed its bf16 gradient over directly (see BceLossFn.backward)
         dy2 = dy.reshape(-1, n)
         if n_pad == n and dy2.dtype != BF16 and dy2.is_contiguous():
             dy2 = dy2.to(BF16)                                   # fp32 scores (classifier): one cast, no padding needed
@@ -115,10 +117,17 @@ class LinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, wv, b_kcontig=False)[:, :ctx.in_shape[-1]]                    # dx = dy W
             dx = dx.reshape(ctx.in_shape).to(ctx.in_dtype)
-        return dx, None, None, None
+        return dx, None, None, None, None
 
 
 def linear(x, lin, out_f32=False):
+    if out_f32 and torch.is_grad_enabled():
+        # fp32 scores (the classifier): autograd insists on an fp32 gradient for them, which the loss would have to produce from its bf16 one and
+        # the backward GEMMs cast straight back (two passes over [B*12, V]).  The output carries a side channel the loss may use instead.
+        side = {}
+        y = LinearFn.apply(x, lin.weight, lin.bias, out_f32, side)
+        y._sam_grad_side = side
+        return y
     return LinearFn.apply(x, lin.weight, lin.bias, out_f32)
 
 
@@ -585,6 +594,16 @@ class PtrScoresFn(Function):
         return dq, dk, None, None
 
 
+_PLACEHOLDERS = {}
+
+
+def _placeholder(device):
+    t = _PLACEHOLDERS.get(device)
+    if t is None:
+        t = _PLACEHOLDERS[device] = torch.zeros((), dtype=torch.float32, device=device)
+    return t
+
+
 class BceLossFn(Function):
     """M4CDecodingBCEWithMaskLoss (sam/task_utils.py:19-30) on the two score blocks; gradient computed in the forward pass"""
 
@@ -597,11 +616,17 @@ class BceLossFn(Function):
         loss, d_fixed, d_ocr = ops.bce_loss(f2, o2, targets.reshape(r, -1), loss_mask.reshape(r).contiguous(), grad_scale, global_count)
         ctx.save_for_backward(d_fixed, d_ocr)
         ctx.shapes, ctx.unit_grad = (fixed.shape, ocr.shape), unit_grad
+        ctx.side = getattr(fixed, "_sam_grad_side", None) if fixed.dtype == torch.float32 else None
         return loss[0]
 
     @staticmethod
     def backward(ctx, g):
         d_fixed, d_ocr = ctx.saved_tensors
         if ctx.unit_grad:      # the caller (Trainer.step) runs loss.backward() itself: upstream gradient is exactly 1, skip three elementwise passes
+            if ctx.side is not None:
+                # the producer of `fixed` (LinearFn via linear(..., out_f32=True)) takes the bf16 gradient through its side channel; what goes through
+                # autograd is a zero-stride fp32 placeholder of the right shape (no kernel, and nothing reads it)
+                ctx.side["dy_bf16"] = d_fixed.view(ctx.shapes[0])
+                return _placeholder(d_ocr.device).expand(ctx.shapes[0]), d_ocr.view(ctx.shapes[1]), None, None, None, None, None
             return d_fixed.view(ctx.shapes[0]), d_ocr.view(ctx.shapes[1]), None, None, None, None, None
         return (d_fixed.view(ctx.shapes[0]) * g).to(torch.float32), (d_ocr.view(ctx.shapes[1]) * g), None, None, None, None, None
