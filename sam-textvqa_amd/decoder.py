@@ -217,28 +217,28 @@ class DecodeSession:
 
     def _fused_plan(self):
         """arguments of sam_greedy_decode_steps over this session's static buffers (after _first), or False when the fused kernel does not apply.
-        Part of the first pass (captured with it): the weights are re-tiled into the MFMA fragment layout here, once per batch (~170 MB of copies,
-        ~1 % of a batch), so a session never decodes with the weights of an earlier training step."""
+        The weights live re-tiled into the MFMA fragment layout in static buffers of the session (see _retile_if_stale)."""
         m, mmt = self.model, self.model.mmt
         r, s = self.rows, self.steps
         if self.beam or s < 2 or not fused_enabled():
             return False
         layers = []
         eps = None
+        srcs = []                                   # the row-major bf16 weights, in the order of self._tiled
         for (layer, bits), (qkv_full, _, _) in zip(self.plan, self.caches):
             att, so, inter, out = layer.attention.self, layer.attention.output, layer.intermediate, layer.output
             wqkv, bqkv, _, _ = _fused_qkv(att)
             d3, d = wqkv.shape
             if d != 768 or inter.dense.weight.shape[0] != 3072 or att.attention_head_size != 64 or d3 != 3 * d:
                 return False
+            srcs += [wqkv, _w(so.dense.weight), _w(inter.dense.weight), _w(out.dense.weight)]
             e1, e2 = float(so.LayerNorm.variance_epsilon), float(out.LayerNorm.variance_epsilon)
             if eps is None:
                 eps = e1
             if e1 != eps or e2 != eps:
                 return False
-            layers.append({"wqkv": ops.tile_weight(wqkv), "bqkv": bqkv, "wo": ops.tile_weight(_w(so.dense.weight)), "bo": so.dense.bias.data, "ln1_g": so.LayerNorm.weight.data, "ln1_b": so.LayerNorm.bias.data,
-                           "w1": ops.tile_weight(_w(inter.dense.weight)), "b1": inter.dense.bias.data, "w2": ops.tile_weight(_w(out.dense.weight)),
-                           "b2": out.dense.bias.data,
+            layers.append({"wqkv": None, "bqkv": bqkv, "wo": None, "bo": so.dense.bias.data, "ln1_g": so.LayerNorm.weight.data, "ln1_b": so.LayerNorm.bias.data,
+                           "w1": None, "b1": inter.dense.bias.data, "w2": None, "b2": out.dense.bias.data,
                            "ln2_g": out.LayerNorm.weight.data, "ln2_b": out.LayerNorm.bias.data, "qkv": qkv_full, "allow": bits})
         if not 1 <= len(layers) <= 8 or self.n > 256 or not 1 <= self.n_ocr <= 64:
             return False
@@ -248,13 +248,25 @@ class DecodeSession:
         wq, _, bq, _, _, _ = _padded_views(pq.weight, pq.bias)
         if wq.shape != (768, 768) or m.classifier.bias is None or pq.bias is None:
             return False
+        srcs += [wc, wq]
+        # fragment-tiled copies of the weights: static buffers of the session, refilled (outside the captured graphs) whenever the bf16 shadows
+        # have changed since -- FlatParams.shadow_epoch, bumped by every optimizer step and every refresh -- and not once per batch (28 strided
+        # copies, 156 us of a 6 ms batch)
+        self._tile_srcs = srcs
+        if getattr(self, "_tiled", None) is None:
+            if torch.cuda.is_current_stream_capturing():
+                return False                         # (cannot happen: the eager round of _capture comes first)
+            self._tiled = [ops.tile_weight(w) for w in srcs]
+            self._tiled_epoch = self._shadow_epoch()
+        for k, l in enumerate(layers):
+            l["wqkv"], l["wo"], l["w1"], l["w2"] = self._tiled[4 * k: 4 * k + 4]
         fixed, dyn = self.out_first
         att0 = self.plan[0][0].attention.self
         desc = {"n_layers": len(layers), "B": r, "N": self.n, "n_enc": self.n - s, "S": s, "H": att0.num_attention_heads, "D": 768, "F": 3072,
                 "V": m.classifier.weight.shape[0], "No": self.n_ocr, "scale": 1.0 / math.sqrt(att0.attention_head_size), "ln_eps": eps,
                 "emb_ln_eps": float(pp.emb_layer_norm.variance_epsilon), "ptr_scale": 1.0 / math.sqrt(m.ocr_ptr_net.query_key_size),
                 "pos_emb": pp.position_embeddings.weight.data, "type_emb": pp.token_type_embeddings.weight.data, "emb_ln_g": pp.emb_layer_norm.weight.data,
-                "emb_ln_b": pp.emb_layer_norm.bias.data, "ans_ln": self.ans_ln, "ocr_ln": self.ocr_ln, "wc": ops.tile_weight(wc), "bc": bc, "wq": ops.tile_weight(wq), "bq": bq, "ptr_k": self.ptr_k,
+                "emb_ln_b": pp.emb_layer_norm.bias.data, "ans_ln": self.ans_ln, "ocr_ln": self.ocr_ln, "wc": self._tiled[-2], "bc": bc, "wq": self._tiled[-1], "bq": bq, "ptr_k": self.ptr_k,
                 "ocr_mask": self.ocr_mask, "prev_inds": self.prev, "fixed_scores": fixed if fixed.is_contiguous() else None, "ld_fixed": fixed.stride(0),
                 "ocr_scores": dyn, "seq_out": self.seq}
         if desc["fixed_scores"] is None:            # a column slice of the padded logits block: same memory, row stride ld_fixed
@@ -262,6 +274,25 @@ class DecodeSession:
         if getattr(self, "_fused_ws", None) is None:
             self._fused_ws = ops.greedy_decode_ws(r, s, len(layers), self.prev.device)
         return layers, desc, self._fused_ws
+
+    def _shadow_epoch(self):
+        flat = getattr(self.model.classifier.weight, "_sam_flat", None)
+        return getattr(flat, "shadow_epoch", None)
+
+    def _retile_if_stale(self):
+        """refill the tiled weight copies when the bf16 shadows changed since they were made (a training step, load_state_dict, ...)"""
+        if not self.fused or getattr(self, "_tiled", None) is None:
+            return
+        ep = self._shadow_epoch()
+        if ep is None or ep != self._tiled_epoch:
+            for dst, w in zip(self._tiled, self._tile_srcs):
+                n, k = w.shape
+                dst[: n // 16].copy_(w[: n // 16 * 16].reshape(n // 16, 16, k // 8, 8).permute(0, 2, 1, 3))
+                if n % 16:
+                    tail = torch.zeros((16, k), dtype=w.dtype, device=w.device)
+                    tail[: n % 16] = w[n // 16 * 16:]
+                    dst[n // 16].copy_(tail.reshape(16, k // 8, 8).permute(1, 0, 2))
+            self._tiled_epoch = ep
 
     def _steps_fused(self):
         """decoding steps 1 .. S-1, one launch (the score blocks, prev_inds and the final hidden states of out_first / seq are completed in place)"""
@@ -305,6 +336,7 @@ class DecodeSession:
         if graph_enabled() and self.graph_first is None:
             self._capture()
             self.load_inputs(batch_dict, force=True)       # (the eager round inside _capture decoded in place on the static train_prev_inds)
+        self._retile_if_stale()
         if not graph_enabled():
             self._first()
             last = self.out_first
@@ -329,6 +361,21 @@ class DecodeSession:
         return self._results(batch_dict, last)
 
     def _capture(self):
+        # Dead sessions (a model and its sessions form a reference cycle: only the cyclic collector frees them) own hipGraphs and their private
+        # pools; a collection that happens to run in the middle of a capture destroys them there, which HIP answers with an error out of a
+        # destructor -- the process aborts (seen as an intermittent "Fatal Python error: Aborted" in the test suite).  Collect now, and keep
+        # the collector off until both captures are done.
+        import gc
+        gc.collect()
+        was_enabled = gc.isenabled()
+        gc.disable()
+        try:
+            self._capture_impl()
+        finally:
+            if was_enabled:
+                gc.enable()
+
+    def _capture_impl(self):
         # one eager round first: lazily-set kernel attributes, workspaces, flat-storage preparation must not happen inside a capture
         cur = torch.cuda.current_stream()
         st = torch.cuda.Stream()

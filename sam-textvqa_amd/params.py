@@ -107,6 +107,7 @@ class FlatParams:
     def refresh_shadows(self):
         ops.cast_bf16(self.flat, self.bf16)
         self._versions = [p._version for p in self.params]
+        self.shadow_epoch = getattr(self, "shadow_epoch", 0) + 1      # consumers that keep derived copies of the shadows (decoder: re-tiled weights) compare it
 
     def ensure_fresh(self):
         """parameters modified in place from Python (load_state_dict, init) bump their version counter; the fused

@@ -230,6 +230,7 @@ class Trainer:
 
     def step(self, batch_dict):
         """one optimisation step; returns the (device, un-synchronised) loss tensor"""
+        self._bump_shadow_epoch()
         if self.use_graph and (self.reducer is None or self._dp_capturable()):
             return self._graph_step(batch_dict)
         return self._eager_step(batch_dict)
@@ -333,6 +334,9 @@ class Trainer:
                 out.extend((k, kk, vv) for kk, vv in sorted(v.items()) if torch.is_tensor(vv))
         return out
 
+    def _bump_shadow_epoch(self):
+        self.flat.shadow_epoch = getattr(self.flat, "shadow_epoch", 0) + 1      # Adam rewrote the bf16 shadows
+
     def _graph_step(self, batch_dict):
         dev = self.flat.flat.device
         items = self._flatten(batch_dict)
@@ -407,6 +411,10 @@ class Trainer:
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
         ops.set_rng_state(self._rng_state)
+        import gc
+        gc.collect()                       # (garbage that owns hipGraphs must not be collected in the middle of the capture: decoder.DecodeSession._capture)
+        gc_was_enabled = gc.isenabled()
+        gc.disable()
         try:
             with torch.cuda.graph(g, stream=self._cap_stream):
                 # first node: fresh dropout masks, the step counter, this step's learning rates and bias corrections -- all on the device
@@ -415,6 +423,8 @@ class Trainer:
                 loss = self._eager_step(bd, sched_dev=self._sched_dev)
                 self._static_loss = loss
         finally:
+            if gc_was_enabled:
+                gc.enable()
             ops.set_rng_state(None)                                           # the captured launches keep the pointer; eager launches go back to by-value
             dropout_clock.offset = saved_offset
         self._graph, self._graph_sig, self._static_in = g, sig, static_in

@@ -252,6 +252,40 @@ def test_persistent_decoding_kernel_at_ragged_batch_sizes(batch, monkeypatch):
         assert torch.equal(a[1], b[1]) and err < 6e-3 and herr < 4e-2, (batch, err, herr)
 
 
+def test_persistent_decoding_kernel_follows_weight_updates(monkeypatch):
+    """the session keeps fragment-tiled copies of the weights; they must be refilled when the parameters change (FlatParams.shadow_epoch): after an
+    in-place update of every layer the captured session decodes with the NEW weights -- same scores as a freshly built per-kernel session"""
+    model, _, shapes = _models()
+    model.decode_cache = True
+    monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
+    monkeypatch.setenv("SAM_DECODE_FUSED", "1")
+    model.__dict__.pop("_sam_decode_sessions", None)
+    bd = _batch(4, shapes, 300, 41, "cuda")
+    with torch.no_grad():
+        before = model(bd)["textvqa_scores"].float().cpu()
+    ses = next(iter(model._sam_decode_sessions.values()))
+    assert ses.fused
+    g = torch.Generator(device="cuda").manual_seed(1)
+    with torch.no_grad():
+        for p in model.mmt.parameters():
+            if p.dim() == 2:
+                p.add_(torch.randn(p.shape, device=p.device, generator=g) * 0.02)
+        model.classifier.weight.add_(torch.randn(model.classifier.weight.shape, device="cuda", generator=g) * 0.02)
+    bd = _batch(4, shapes, 300, 41, "cuda")
+    with torch.no_grad():
+        after = model(bd)["textvqa_scores"].float().cpu()                      # the SAME session (captured graphs), new weights
+    assert next(iter(model._sam_decode_sessions.values())) is ses
+    monkeypatch.setenv("SAM_DECODE_FUSED", "0")
+    model.__dict__.pop("_sam_decode_sessions", None)
+    bd = _batch(4, shapes, 300, 41, "cuda")
+    with torch.no_grad():
+        want = model(bd)["textvqa_scores"].float().cpu()
+    live = want > -9000
+    err = ((after - want).abs()[live].max() / want[live].abs().max()).item()
+    moved = ((before - want).abs()[live].max() / want[live].abs().max()).item()
+    assert err < 6e-3 and moved > 10 * err, (err, moved)
+
+
 def test_greedy_decode_steps_rejects_what_it_is_not_built_for():
     from sam_textvqa_amd import ops
     from sam_textvqa_amd._capi import SamHipError
