@@ -304,7 +304,7 @@ int sam_beam_step(const float* fixed_scores, int64_t ld_fixed, const float* ocr_
  *   layers[l]: bf16 weights (wqkv = q|k|v stacked, [3D, D]) in the FRAGMENT-TILED layout [out / 16][in / 8][16][8] -- element (o, i) at
  *     ((o / 16 * (in / 8) + i / 8) * 16 + o % 16) * 8 + i % 8, `out` zero-padded to a multiple of 16: what an MFMA operand load of 16 rows reads as
  *     one contiguous kilobyte (row-major rows cost one tag lookup per lane: 6.5 us per phase) --, fp32 biases and LayerNorm vectors; qkv = that layer's
- *     bf16 [B, N, 3D] row-major cache as left by the first pass (sam_gemm_bf16 of all rows); allow = the layer's bits [B, Hm, N, ceil(N/32)] with strides.
+ *     bf16 [B, N, 3D] row-major cache as left by the first pass (sam_gemm_bf16 of all rows), rows n_enc + t are written by the launch; allow = the layer's bits [B, Hm, N, ceil(N/32)] with strides.
  *   ans_ln bf16 [V, D], ocr_ln bf16 [B*No, D]: the two step-invariant LayerNorms of PrevPredEmbeddings; pos_emb / type_emb fp32 rows (ld in elements);
  *   wc bf16 [V -> multiple of 16, D] and wq bf16 [D, D], both fragment-tiled as above; bc, bq fp32; ptr_k bf16 [B, No, D] the pointer network's keys; ocr_mask u8 [B, No]; ptr_scale = 1/sqrt(D);
  *   prev_inds int64 [B, S]; fixed_scores fp32 [B, S, ld_fixed], ocr_scores fp32 [B, S, No]; seq_out (may be NULL) bf16 [B, N, D] receives the final

@@ -56,7 +56,7 @@ __device__ __forceinline__ unsigned ld4_l2(rsrc_t r, int off) { return __builtin
 struct DLayer {
   const bf16_t *wqkv, *wo, *w1, *w2;
   const float *bqkv, *bo, *b1, *b2, *g1, *be1, *g2, *be2;
-  bf16_t* qkv;
+  bf16_t* qkv;                      // [B, N, 3D]: the first pass's q|k|v rows; rows n_enc + t are written here
   const uint32_t* allow;
   long long allow_sb, allow_sh;
 };
@@ -250,12 +250,35 @@ __device__ __forceinline__ void finalize_row(const DArgs& a, const Grp& G, int r
 // attention of decoder row t for (local row, head h): one wave.  Lane (kg = lane >> 3, dc = lane & 7) takes the 16-byte chunk dc of keys kg, kg + 8, ...:
 // every load instruction covers eight whole 128-byte head rows; a key's score is completed across its eight lanes, the probabilities stay in the
 // lanes that load the matching value chunks, and the eight key groups are added at the end.  NI = ceil(N / 8) iterations.
+// cross-lane adds inside a row of 16 lanes by DPP (one VALU cycle each) instead of ds_bpermute: quad_perm [1,0,3,2] / [2,3,0,1], row_half_mirror (lane i <-> 7 - i
+// inside 8 lanes: the quads already hold equal sums), row_ror:8 (lane i <-> i ^ 8)
+#define SAM_DPP(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xf, 0xf, false))
+__device__ __forceinline__ float sum8(float d) {            // sum over the 8 lanes (l & ~7) .. (l | 7), result in all of them
+  d += SAM_DPP(d, 0xB1);
+  d += SAM_DPP(d, 0x4E);
+  d += SAM_DPP(d, 0x141);
+  return d;
+}
+
 // keys / values of every cache row before the current one, all loads in flight at once
 template <int NI>
-__device__ __forceinline__ void attn_load(uint4 (&kf)[NI], uint4 (&vf)[NI], const DArgs& a, const DLayer& L, const Grp& G, int row, int h, int t) {
-  const int lane = threadIdx.x & 63, kg = lane >> 3, dc = lane & 7, b = G.b0 + row;
+struct AttnCur { uint4 q, k, v; uint32_t aw[NI / 4]; };      // the current row's q / k / v chunk of this lane and the row's allow words (32 keys each)
+template <int NI>
+__device__ __forceinline__ void attn_load(uint4 (&kf)[NI], uint4 (&vf)[NI], AttnCur<NI>& c, const DArgs& a, const DLayer& L, const Grp& G, int li, int row, int h, int t) {
+  const int lane = threadIdx.x & 63, b = G.b0 + row, kg = lane >> 3, dc = lane & 7;
   const int qc = a.n_enc + t;
   const bf16_t* base = L.qkv + (long long)b * a.N * (3 * D) + h * HD + dc * 8;
+  {   // requested FIRST: the score loop needs them before anything else, and loads return in order
+    const bf16_t* cur = base + (long long)qc * (3 * D);                  // the row phase Q has just written
+    c.q = *reinterpret_cast<const uint4*>(cur);
+    c.k = *reinterpret_cast<const uint4*>(cur + D);
+    c.v = *reinterpret_cast<const uint4*>(cur + 2 * D);
+    const uint32_t* ap = L.allow + b * L.allow_sb + h * L.allow_sh + (long long)qc * a.NWORDS;
+#pragma unroll
+    for (int w = 0; w < NI / 4; ++w) c.aw[w] = ap[min(w, a.NWORDS - 1)];
+  }
+  // (a head-major copy of the cache -- [B, H, N, 64], one (sample, head)'s rows a contiguous 23 KB stream instead of 128-byte pieces 4.6 KB apart --
+  // was built and measured: the keys / values arrive after 6.4 us either way, the XCD's share of the fabric, and the copy cost 0.22 ms per batch)
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const bf16_t* rp = base + (long long)min(kg + 8 * i, max(qc - 1, 0)) * (3 * D);
@@ -264,14 +287,12 @@ __device__ __forceinline__ void attn_load(uint4 (&kf)[NI], uint4 (&vf)[NI], cons
   }
 }
 template <int NI>
-__device__ __forceinline__ void attn_finish(const uint4 (&kf)[NI], const uint4 (&vf)[NI], const DArgs& a, const DLayer& L, const Grp& G, int li, int row, int h, int t) {
+__device__ __forceinline__ void attn_finish(const uint4 (&kf)[NI], const uint4 (&vf)[NI], const AttnCur<NI>& c, const DArgs& a, const DLayer& L, const Grp& G, int li, int row, int h,
+                                            int t) {
   const int lane = threadIdx.x & 63, kg = lane >> 3, dc = lane & 7, b = G.b0 + row;
   const int qc = a.n_enc + t, nk = qc + 1;
-  const bf16_t* base = L.qkv + (long long)b * a.N * (3 * D) + h * HD + dc * 8;
-  const bf16_t* cur = base + (long long)qc * (3 * D);                  // the row phase Q has just written
-  const uint4 qu = *reinterpret_cast<const uint4*>(cur), kcur = *reinterpret_cast<const uint4*>(cur + D), vcur = *reinterpret_cast<const uint4*>(cur + 2 * D);
+  const uint4 qu = c.q, kcur = c.k, vcur = c.v;
   const float q8[8] = {bf_lo(qu.x), bf_hi(qu.x), bf_lo(qu.y), bf_hi(qu.y), bf_lo(qu.z), bf_hi(qu.z), bf_lo(qu.w), bf_hi(qu.w)};
-  const uint32_t* ap = L.allow + b * L.allow_sb + h * L.allow_sh + (long long)qc * a.NWORDS;
   float s[NI];
   float mx = -INFINITY;
 #pragma unroll
@@ -281,8 +302,8 @@ __device__ __forceinline__ void attn_finish(const uint4 (&kf)[NI], const uint4 (
     float d = q8[0] * bf_lo(u.x);
     d = fmaf(q8[1], bf_hi(u.x), d); d = fmaf(q8[2], bf_lo(u.y), d); d = fmaf(q8[3], bf_hi(u.y), d);
     d = fmaf(q8[4], bf_lo(u.z), d); d = fmaf(q8[5], bf_hi(u.z), d); d = fmaf(q8[6], bf_lo(u.w), d); d = fmaf(q8[7], bf_hi(u.w), d);
-    d += __shfl_xor(d, 1); d += __shfl_xor(d, 2); d += __shfl_xor(d, 4);
-    const bool valid = j < nk && ((ap[min(j, a.N - 1) >> 5] >> (j & 31)) & 1u);
+    d = sum8(d);
+    const bool valid = j < nk && ((c.aw[i / 4] >> (j & 31)) & 1u);      // (key 8 i + kg lies in word i / 4)
     s[i] = valid ? d * a.scale_log2 : -INFINITY;
     mx = fmaxf(mx, s[i]);
   }
@@ -292,7 +313,8 @@ __device__ __forceinline__ void attn_finish(const uint4 (&kf)[NI], const uint4 (
   for (int i = 0; i < NI; ++i) {
     const float p = s[i] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s[i] - mx);
     l += p;
-    const uint4 u = (kg + 8 * i) == qc ? vcur : vf[i];
+    uint4 u = (kg + 8 * i) == qc ? vcur : vf[i];
+    if (p == 0.f) u = uint4{0u, 0u, 0u, 0u};                    // (rows past the current one are never meant to be read: whatever they hold, 0 x it must be 0)
     acc[0] = fmaf(p, bf_lo(u.x), acc[0]); acc[1] = fmaf(p, bf_hi(u.x), acc[1]); acc[2] = fmaf(p, bf_lo(u.y), acc[2]); acc[3] = fmaf(p, bf_hi(u.y), acc[3]);
     acc[4] = fmaf(p, bf_lo(u.z), acc[4]); acc[5] = fmaf(p, bf_hi(u.z), acc[5]); acc[6] = fmaf(p, bf_lo(u.w), acc[6]); acc[7] = fmaf(p, bf_hi(u.w), acc[7]);
   }
@@ -442,8 +464,9 @@ __global__ __launch_bounds__(NT, 1) void decode_steps_kernel(DArgs a) {
       // A
       for (int task = wg; task < G.nloc * a.H; task += nwaves) {
         uint4 kf[NI], vf[NI];
-        attn_load<NI>(kf, vf, a, L, G, task / a.H, task % a.H, t);
-        attn_finish<NI>(kf, vf, a, L, G, li, task / a.H, task % a.H, t);
+        AttnCur<NI> cur;
+        attn_load<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
+        attn_finish<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
       }
       if (!xcd_sync(a, G, nblk, epoch)) return;
       // O: split-K partials
