@@ -93,7 +93,7 @@ int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uin
  *   SAM_EPI_BIAS_GELU         aux_out = acc + bias ; C = gelu_erf(aux_out)        BertIntermediate via :678
  *   SAM_EPI_BIAS_DROPOUT_RES  C = dropout(acc + bias) + residual[m,n]             BertSelfOutput :653 / BertOutput :680 (pre-LN)
  *   SAM_EPI_DGELU             C = acc * gelu_erf'(aux_in[m,n])                    backward of BertIntermediate
- *   SAM_EPI_BIAS_GELU_GRAD    aux_out = gelu_erf'(acc + bias) ; C = gelu_erf(acc + bias)     BertIntermediate in TRAINING: the derivative shares the
+ *   SAM_EPI_BIAS_GELU_GRAD    aux_out = gelu_erf'(acc + bias) (skipped when aux_out is NULL: inference) ; C = gelu_erf(acc + bias)     BertIntermediate in TRAINING: the derivative shares the
  *                             exponential with the activation (two extra FMAs); the backward then needs no transcendental at all:
  *   SAM_EPI_MUL_AUX           C = acc * aux_in[m,n]                               backward of BertIntermediate from the stored derivative
  * bias may be NULL (treated as 0); dropout draws 8 x 16 bits per (row, col/8) from the counter hash so the backward regenerates it. */

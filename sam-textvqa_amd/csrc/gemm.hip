@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, i
       float d[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
-      *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
+      if (p.aux_out) *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
     }
     if (EPI == SAM_EPI_DGELU) {
       const uint2 x = *reinterpret_cast<const uint2*>(p.aux_in + (int64_t)m * p.ld_aux + n);
@@ -514,7 +514,9 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   a.defer_reduce = d->defer_reduce;
   a.split_used = const_cast<int32_t*>(&d->split_k_used);
   SAM_REQUIRE(!d->bias_grad || (!d->a_kcontig && !d->b_kcontig), "sam_gemm_bf16: bias_grad is a wgrad-layout (0,0) feature");
-  if (d->epilogue == SAM_EPI_BIAS_GELU || d->epilogue == SAM_EPI_BIAS_GELU_GRAD) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
+  if (d->epilogue == SAM_EPI_BIAS_GELU) SAM_REQUIRE(d->aux_out && d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU needs aux_out");
+  if (d->epilogue == SAM_EPI_BIAS_GELU_GRAD) SAM_REQUIRE(!d->aux_out || d->ld_aux % 4 == 0, "sam_gemm_bf16: BIAS_GELU_GRAD: ld_aux must be a multiple of 4");      // aux_out NULL = do not store GELU'"'"'
+
   if (d->epilogue == SAM_EPI_DGELU || d->epilogue == SAM_EPI_MUL_AUX) SAM_REQUIRE(d->aux_in && d->ld_aux % 4 == 0, "sam_gemm_bf16: DGELU / MUL_AUX need aux_in");
   if (d->epilogue == SAM_EPI_BIAS_DROPOUT_RES) SAM_REQUIRE(!d->residual || d->ldr % 4 == 0, "sam_gemm_bf16: bad residual ld");
   int want_split = (d->split_k == 1) ? 0 : d->split_k;

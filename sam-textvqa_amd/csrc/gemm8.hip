@@ -237,7 +237,7 @@ __device__ __forceinline__ void defer_slice(const GemmArgs& p, const f32x4 (&pac
     float d[W];
 #pragma unroll
     for (int r = 0; r < W; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
-    if (ok) {
+    if (ok && p.aux_out) {                  // (aux_out NULL: inference -- the 71.6 MB derivative block of an MMT-size FFN1 is not written)
       bf16_t* dst = p.aux_out + (int64_t)m * p.ld_aux + n;
       if constexpr (PART == 0) *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7]));
       else *reinterpret_cast<uint2*>(dst) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));

@@ -129,7 +129,7 @@ __device__ __forceinline__ void gemm_epilogue_impl(const GemmArgs& p, const f32x
         float d[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
-        if (FULL || (m < p.M && n < p.N))
+        if (p.aux_out && (FULL || (m < p.M && n < p.N)))          // (aux_out NULL: inference, the derivative is not wanted)
           *reinterpret_cast<uint2*>(p.aux_out + (int64_t)m * p.ld_aux + n) = make_uint2(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]));
       }
       if (EPI == SAM_EPI_DGELU) {
@@ -243,7 +243,7 @@ __device__ __forceinline__ void gemm_epilogue8_impl(const GemmArgs& p, const f32
         float d[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = gelu_erf_and_grad(v[r], d[r]);
-        if (ok)
+        if (ok && p.aux_out)
           *reinterpret_cast<uint4*>(p.aux_out + (int64_t)m * p.ld_aux + n) =
               make_uint4(pack_bf16x2(d[0], d[1]), pack_bf16x2(d[2], d[3]), pack_bf16x2(d[4], d[5]), pack_bf16x2(d[6], d[7]));
       }

@@ -266,8 +266,7 @@ def _layer_tail(layer, ctx, x):
     so, inter, out = layer.attention.output, layer.intermediate, layer.output
     z1 = ops.gemm(ctx, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x)
     a, _, _ = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
-    pre = torch.empty((x.shape[0], inter.dense.weight.shape[0]), dtype=BF16, device=x.device)
-    h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=inter.dense.bias, aux_out=pre)   # (the 8-wave kernels carry this form; `pre` is scratch here)
+    h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=inter.dense.bias)      # (the 8-wave kernels carry this form; no aux_out: the derivative is not stored)
     z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a)
     return ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)[0]
 
