@@ -122,7 +122,7 @@ typedef struct sam_gemm_desc {
   int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
-/* up to 8 independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C, SAM_EPI_NONE, no split) in ONE grid: the four
+/* up to 12 independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C, SAM_EPI_NONE, no split) in ONE grid: the four
  * weight gradients of an encoder layer (dWqkv, dWo, dW1, dW2: 432 tiles of 128x128) fill the 512 resident block slots in a single
  * round, which makes split-K and its reduction pass unnecessary.  bias_grad is honoured per problem. */
 int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);

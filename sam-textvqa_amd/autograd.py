@@ -4,6 +4,7 @@ Parameter gradients are NOT returned to autograd: wgrad GEMMs and the fused redu
 flat gradient buffer (params.py).  Each Function receives one parameter tensor as an `anchor` input only so that its
 output requires grad even when the activation input does not."""
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -199,6 +200,7 @@ class EmbedLayerNormFn(Function):
     def backward(ctx, dy):
         e, mean, rstd, ids, type_ids = ctx.saved_tensors
         table_w, pos_w, tt_w, ln = ctx.params
+        DeferredWgrads.flush()                                  # the encoder layers above this embedding block have all run their backward
         if dy.dtype != BF16 or not dy.is_contiguous():
             dy = dy.to(BF16).contiguous()
         d_e, _ = ops.layernorm_bwd(dy, e, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad)
@@ -449,6 +451,39 @@ def region_done(rid):
     red.mark_done(rid)
 
 
+class DeferredWgrads:
+    """weight gradients of layers marked `_sam_defer_wgrad` (TextBert's three 1280-row layers: a grouped launch of four 18-GFLOP problems fills 216 of
+    512 block slots for 38 us, three times in a row on the tail's critical chain) are queued by EncoderLayerFn.backward and run as ONE grouped launch of up
+    to 12 problems when the embedding block below them starts its backward (EmbedLayerNormFn) -- or, failing that, when the Trainer joins the backward.
+    Their data-parallel regions are reported done after that launch, in backward order."""
+    jobs, layers, acc = [], [], None
+
+    @classmethod
+    def add(cls, layer, jobs, acc):
+        if cls.jobs and (cls.acc != acc or len(cls.jobs) + len(jobs) > 12):
+            cls.flush()
+        cls.jobs, cls.acc = cls.jobs + list(jobs), acc
+        cls.layers.append(layer)
+
+    @classmethod
+    def flush(cls):
+        if not cls.jobs:
+            return
+        jobs, layers, acc = cls.jobs, cls.layers, cls.acc
+        cls.jobs, cls.layers, cls.acc = [], [], None
+        ops.wgrad_grouped(jobs, accumulate=acc)
+        for layer in layers:
+            region_done(getattr(layer, "_sam_region_id", None))
+
+    @classmethod
+    def clear(cls):
+        cls.jobs, cls.layers, cls.acc = [], [], None
+
+
+def defer_wgrad_enabled():
+    return os.environ.get("SAM_DEFER_TB_WGRAD", "1") != "0"
+
+
 # ------------------------------------------------------------------------------------------------ encoder layer
 class EncoderLayerFn(Function):
     """One BERT-style encoder layer (spatial or plain — the difference is entirely in `allow`), forward and backward,
@@ -493,11 +528,21 @@ class EncoderLayerFn(Function):
         # read-modify-write; without the mark (plain autograd use, gradient accumulation) everything accumulates as usual
         acc = not getattr(layer, "_sam_grad_fresh", False)
         layer._sam_grad_fresh = False
+        defer = bool(getattr(layer, "_sam_defer_wgrad", False)) and defer_wgrad_enabled()
         if ctx.coarse:
             *saved, allow = ctx.saved_tensors
-            dx = torchops.ns().encoder_layer_bwd(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch, att.num_attention_heads, ctx.scale,
-                                                 ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
-            region_done(getattr(layer, "_sam_region_id", None))
+            if defer:
+                dx, dy2, dpre, dy1, dqkv = torchops.ns().encoder_layer_bwd_nowgrad(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch,
+                                                                                   att.num_attention_heads, ctx.scale, ctx.p_attn, p_hid,
+                                                                                   [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
+                _, _, dwqkv, dbqkv = _fused_qkv(att)
+                x_, ctx_, a_, h_ = saved[0], saved[2], saved[8], saved[10]
+                DeferredWgrads.add(layer, [(dy2, h_, out.dense.weight.grad, None), (dpre, a_, inter.dense.weight.grad, inter.dense.bias.grad),
+                                           (dy1, ctx_, so.dense.weight.grad, None), (dqkv, x_, dwqkv, dbqkv)], acc)
+            else:
+                dx = torchops.ns().encoder_layer_bwd(dy, saved, allow, _layer_params(layer), _layer_grads(layer), ctx.batch, att.num_attention_heads, ctx.scale,
+                                                     ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
+                region_done(getattr(layer, "_sam_region_id", None))
             return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
         x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
         wqkv, _, dwqkv, dbqkv = _fused_qkv(att)
@@ -519,9 +564,13 @@ class EncoderLayerFn(Function):
         # ---- attention core + fused QKV projection
         dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn)
         wgrads.append((dqkv, x, dwqkv, dbqkv))
-        ops.wgrad_grouped(wgrads, accumulate=acc)
+        if defer:
+            DeferredWgrads.add(layer, wgrads, acc)
+        else:
+            ops.wgrad_grouped(wgrads, accumulate=acc)
         dx = ops.gemm(dqkv, wqkv, b_kcontig=False, epilogue=capi.EPI_BIAS_DROPOUT_RES, residual=dz1) if ctx.needs_input_grad[0] else None
-        region_done(getattr(layer, "_sam_region_id", None))     # this layer's gradients are final: its bucket may go out now
+        if not defer:
+            region_done(getattr(layer, "_sam_region_id", None))     # this layer's gradients are final: its bucket may go out now
         return dx, None, None, None, None, None, None
 
 

@@ -205,15 +205,15 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   /
   gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT>(p, blockIdx.x);
 }
 
-// Grouped launch: up to 8 independent problems of the same kind in ONE grid (block ranges start at multiples of 8 so the XCD-aware
+// Grouped launch: up to 12 independent problems of the same kind in ONE grid (block ranges start at multiples of 8 so the XCD-aware
 // tile remap still sees its hardware XCD).  Used for the four weight-gradient GEMMs of an encoder layer: 36+108+144+144 = 432 tiles
 // fill the 512 block slots in a single round, so no split-K (and no partial-sum reduction pass) is needed at all.
-struct GroupArgs { GemmArgs a[8]; int start[9]; int count; };
+struct GroupArgs { GemmArgs a[SAM_MAX_GROUP]; int start[SAM_MAX_GROUP + 1]; int count; };
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupArgs g) {
   int prob = 0;
 #pragma unroll
-  for (int q = 1; q < 8; ++q)
+  for (int q = 1; q < SAM_MAX_GROUP; ++q)
     if (q < g.count && (int)blockIdx.x >= g.start[q]) prob = q;
   const int local = blockIdx.x - g.start[prob];
   if (local >= g.a[prob].tiles_m * g.a[prob].tiles_n) return;     // padding block
@@ -412,7 +412,7 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
 }  // namespace
 
 extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream) {
-  SAM_REQUIRE(descs && count >= 1 && count <= 8, "sam_gemm_bf16_grouped: 1..8 problems");
+  SAM_REQUIRE(descs && count >= 1 && count <= SAM_MAX_GROUP, "sam_gemm_bf16_grouped: 1..%d problems", SAM_MAX_GROUP);
   GroupArgs g = {};
   g.count = count;
   int total = 0;
@@ -472,7 +472,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
 }
 
 extern "C" int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count) {
-  if (!descs || count < 1 || count > 8) return 0;
+  if (!descs || count < 1 || count > SAM_MAX_GROUP) return 0;
   int tiles = 0;
   for (int q = 0; q < count; ++q) tiles += ((descs[q].M + 255) / 256) * ((descs[q].N + 255) / 256);
   return gemm8w_ws_bytes(tiles);

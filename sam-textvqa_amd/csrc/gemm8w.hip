@@ -1,4 +1,4 @@
-// Grouped weight-gradient GEMM on the 8-wave core (gfx950): dW_p += dy_p^T x_p (and db_p += colsum(dy_p)) for up to 8 problems in ONE launch --
+// Grouped weight-gradient GEMM on the 8-wave core (gfx950): dW_p += dy_p^T x_p (and db_p += colsum(dy_p)) for up to 12 problems in ONE launch --
 // the four weight gradients of an encoder layer (sam/sa_m4c.py:554-560,653,678-680 in the backward direction).
 //
 // Both operands are k-strided (the contraction index R = B*N token rows is the slow index of dy [R, M] and x [R, N]): 64-column panel images in LDS,
@@ -30,8 +30,8 @@ struct WProb {
   int M, N, K, tiles_m, tiles_n, accumulate;
 };
 struct WArgs {
-  WProb p[8];
-  int tile_start[9];
+  WProb p[samgemm::SAM_MAX_GROUP];
+  int tile_start[samgemm::SAM_MAX_GROUP + 1];
   int count, split, dbg;
   float* ws;           // [tiles][2] slots of SLOT_FLOATS
   unsigned* flags;     // [tiles][2], zero between launches
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
   const int gtile = item / w.split, half = item - gtile * w.split;
   int pi = 0;
 #pragma unroll
-  for (int q = 1; q < 8; ++q)
+  for (int q = 1; q < samgemm::SAM_MAX_GROUP; ++q)
     if (q < w.count && gtile >= w.tile_start[q]) pi = q;
   const WProb& P = w.p[pi];
   const int tile = gtile - w.tile_start[pi];

@@ -83,8 +83,8 @@ Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOp
 // dW += dy^T x (and db += colsum(dy)) for up to 8 jobs in one launch
 struct WgradJob { const Tensor* dy; const Tensor* x; const Tensor* dw; const Tensor* db; };
 void wgrad_grouped(const std::vector<WgradJob>& jobs, bool accumulate = true) {
-  sam_gemm_desc d[8] = {};
-  TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 8, "wgrad_grouped: 1..8 jobs");
+  sam_gemm_desc d[12] = {};
+  TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 12, "wgrad_grouped: 1..12 jobs");
   for (size_t q = 0; q < jobs.size(); ++q) {
     const WgradJob& j = jobs[q];
     d[q].M = (int32_t)j.dy->size(1); d[q].N = (int32_t)j.x->size(1); d[q].K = (int32_t)j.dy->size(0);
@@ -382,8 +382,8 @@ std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::
 }
 
 // grads: same order as params, fp32 views into the flat gradient buffer (accumulated in place).  Returns dx (undefined-size-0 when !need_dx).
-Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch, int64_t heads,
-                         double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate) {
+static std::vector<Tensor> encoder_layer_bwd_impl(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch,
+                                                  int64_t heads, double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate, bool defer_wgrad) {
   // accumulate = false: every one of the twelve gradients is OVERWRITTEN (each is written exactly once by this call) -- the caller then need not
   // zero them before the backward pass, and the weight-gradient kernels skip the read half of their read-modify-write
   TORCH_CHECK(saved.size() == S_COUNT && params.size() == P_COUNT && grads.size() == P_COUNT, "encoder_layer_bwd: bad list sizes");
@@ -405,10 +405,31 @@ Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor
   // ---- attention core + fused QKV projection
   Tensor dqkv = attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
   const Tensor dw2 = grads[P_W2], dw1 = grads[P_W1], db1 = grads[P_B1], dwo = grads[P_WO], dwqkv = grads[P_WQKV], dbqkv = grads[P_BQKV];
-  wgrad_grouped({{&dy2, &h, &dw2, nullptr}, {&dpre, &a, &dw1, &db1}, {&dy1, &ctx, &dwo, nullptr}, {&dqkv, &x, &dwqkv, &dbqkv}}, accumulate);
-  if (!need_dx) return at::empty({0}, x.options());
-  o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz1;
-  return gemm(dqkv, params[P_WQKV], true, false, o);
+  // defer_wgrad: the four weight gradients are left to the caller, which runs them for several layers in ONE grouped launch (TextBert's three
+  // 1280-row layers: 3 x 38 us of launches that cannot fill the chip -> one); the gradient operands come back with dx
+  if (!defer_wgrad) wgrad_grouped({{&dy2, &h, &dw2, nullptr}, {&dpre, &a, &dw1, &db1}, {&dy1, &ctx, &dwo, nullptr}, {&dqkv, &x, &dwqkv, &dbqkv}}, accumulate);
+  Tensor dx = at::empty({0}, x.options());
+  if (need_dx) {
+    o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.residual = &dz1;
+    dx = gemm(dqkv, params[P_WQKV], true, false, o);
+  }
+  if (defer_wgrad) return {dx, dy2, dpre, dy1, dqkv};
+  return {dx};
+}
+Tensor encoder_layer_bwd(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch, int64_t heads,
+                         double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate) {
+  return encoder_layer_bwd_impl(dy_in, saved, allow, params, grads, batch, heads, scale, p_attn, p_hid, seeds, need_dx, accumulate, false)[0];
+}
+std::vector<Tensor> encoder_layer_bwd_nowgrad(const Tensor& dy_in, at::TensorList saved, const Tensor& allow, at::TensorList params, at::TensorList grads, int64_t batch,
+                                              int64_t heads, double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate) {
+  return encoder_layer_bwd_impl(dy_in, saved, allow, params, grads, batch, heads, scale, p_attn, p_hid, seeds, need_dx, accumulate, true);
+}
+// dW_q (+)= dy_q^T x_q (and db_q (+)= column sums of dy_q) for up to 12 problems in one launch
+void wgrad_grouped_op(at::TensorList dys, at::TensorList xs, at::TensorList dws, at::TensorList dbs, bool accumulate) {
+  TORCH_CHECK(dys.size() == xs.size() && dys.size() == dws.size() && dys.size() == dbs.size(), "wgrad_grouped: list sizes differ");
+  std::vector<WgradJob> jobs;
+  for (size_t q = 0; q < dys.size(); ++q) jobs.push_back({&dys[q], &xs[q], &dws[q], dbs[q].numel() ? &dbs[q] : nullptr});
+  wgrad_grouped(jobs, accumulate);
 }
 
 // ---------------------------------------------------------------------------------------------------------------- fine-grained op wrappers
@@ -463,6 +484,9 @@ TORCH_LIBRARY(sam_hip, m) {
         "float eps2) -> Tensor[]");
   m.def("encoder_layer_bwd(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
         "float p_hid, int[] seeds, bool need_dx, bool accumulate) -> Tensor");
+  m.def("encoder_layer_bwd_nowgrad(Tensor dy, Tensor[] saved, Tensor allow, Tensor[] params, Tensor(a!)[] grads, int batch, int heads, float scale, float p_attn, "
+        "float p_hid, int[] seeds, bool need_dx, bool accumulate) -> Tensor[]");
+  m.def("wgrad_grouped(Tensor[] dys, Tensor[] xs, Tensor(a!)[] dws, Tensor(b!)[] dbs, bool accumulate) -> ()");
 }
 
 TORCH_LIBRARY_IMPL(sam_hip, CompositeExplicitAutograd, m) {      // no tensor arguments to dispatch on
@@ -479,6 +503,8 @@ TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under
   m.impl("layernorm_bwd", layernorm_bwd_op);
   m.impl("encoder_layer_fwd", encoder_layer_fwd);
   m.impl("encoder_layer_bwd", encoder_layer_bwd);
+  m.impl("encoder_layer_bwd_nowgrad", encoder_layer_bwd_nowgrad);
+  m.impl("wgrad_grouped", wgrad_grouped_op);
   m.impl("pack_masks", pack_masks);
   m.impl("mask_bits_prefix_lm", mask_bits_prefix_lm);
   m.impl("mask_bits_from_additive", mask_bits_from_additive);

@@ -8,7 +8,7 @@ from bisect import bisect
 import torch
 
 from . import ops, parallel
-from .autograd import BceLossFn, dropout_clock
+from .autograd import BceLossFn, DeferredWgrads, dropout_clock
 from .params import prepare
 
 
@@ -287,6 +287,7 @@ class Trainer:
             # whatever the LayerNorm backwards queued points into workspaces of a backward pass that no longer exists (under capture: into the
             # graph's private pool): drop it, or the next step's flush would reduce stale partial sums into dgamma / dbeta / dbias
             self._ln_clear()
+            DeferredWgrads.clear()
             parallel.active_reducer = None
             raise
         finally:
@@ -295,6 +296,7 @@ class Trainer:
         side = getattr(model, "_side_stream", None)
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
+        DeferredWgrads.flush()                                  # (normally empty: TextBert's embedding block flushed it in its backward)
         parallel.active_reducer = None
         if defer_ln:
             self._ln_flush()

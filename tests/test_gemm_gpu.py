@@ -255,8 +255,19 @@ def test_grouped_wgrad_matches_individual():
         assert_close_bf16(dw, rw, ulps=0, name="grouped wgrad")
         if db is not None:
             assert_close_bf16(db, rb, ulps=0, name="grouped bias grad")
+    # twelve problems in one launch (three layers' weight gradients: autograd.DeferredWgrads): every gradient gets its own three contributions
+    for _, _, dw, db in jobs:
+        dw.zero_()
+        if db is not None:
+            db.zero_()
+    trip = [(dy, x, dw.clone(), None if db is None else db.clone()) for _ in range(3) for dy, x, dw, db in jobs]
+    ops.wgrad_grouped(trip)
+    for k, (dy, x, dw, db) in enumerate(trip):
+        assert_close_bf16(dw, dy.float().t() @ x.float(), ulps=0, name="12-problem grouped wgrad %d" % k)
+        if db is not None:
+            assert_close_bf16(db, dy.float().sum(0), ulps=0, name="12-problem grouped bias grad %d" % k)
     with pytest.raises(capi.SamHipError):
-        ops.wgrad_grouped(jobs * 3)         # more than 8 problems
+        ops.wgrad_grouped(jobs * 4)         # more than 12 problems
 
 
 def _wgrad_jobs(R, shapes, seed0=0, bias=(1, 3)):
