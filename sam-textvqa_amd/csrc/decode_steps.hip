@@ -442,7 +442,8 @@ __global__ __launch_bounds__(NT, 1) void decode_steps_kernel(DArgs a) {
   float* part = partbuf(a, G);
   // (Tried: requesting a wave's first-task weight fragments -- and the cache rows below the current one -- BEFORE it arrives at the preceding
   // barrier, to keep the fabric streaming through the barriers.  The register arrays that have to stay live around the loop pushed the kernel
-  // over 512 registers per lane (130-820 spilled, depending on how much was prefetched) and the step got slower: 360 us against 330 us.)
+  // over 512 registers per lane (130-820 spilled, depending on how much was prefetched) and the step got slower: 360 us against 330 us.  A small
+  // version -- the first 8 of 24 k-steps, requested inside the barrier after the stores have drained -- fits, and is neutral: 5.58 against 5.60 ms.)
   const int QT = 3 * D / 16, OT = (D / 16) * KSPLIT, GT = F / 16, CT = (a.V + 15) >> 4;
   for (int row = wg; row < G.nloc; row += nwaves) embed_row(a, G, row, a.t_begin, a.prev[(long long)(G.b0 + row) * a.S + a.t_begin]);
   if (!xcd_sync(a, G, nblk, epoch)) return;
