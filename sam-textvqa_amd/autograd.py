@@ -460,6 +460,8 @@ class DeferredWgrads:
 
     @classmethod
     def add(cls, layer, jobs, acc):
+        if any(l is layer for l in cls.layers):
+            cls.clear()          # a backward pass that never reached its flush (it raised): its operands are stale, this pass recomputes them
         if cls.jobs and (cls.acc != acc or len(cls.jobs) + len(jobs) > 12):
             cls.flush()
         cls.jobs, cls.acc = cls.jobs + list(jobs), acc
