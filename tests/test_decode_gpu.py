@@ -286,6 +286,45 @@ def test_persistent_decoding_kernel_follows_weight_updates(monkeypatch):
     assert err < 6e-3 and moved > 10 * err, (err, moved)
 
 
+def test_decoding_between_training_steps_uses_the_current_weights(monkeypatch):
+    """train (captured step) -> decode (captured session, persistent kernel) -> train -> decode: the session's tiled weight copies follow the optimizer
+    (Trainer.step bumps FlatParams.shadow_epoch), so the second decode equals what a freshly built per-kernel session computes from the updated weights"""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    from tests.test_model_gpu import _small_full_model
+    shapes = (20, 100, 50, 12)
+    model, _ = _small_full_model(3, ("n", "s", "s"), shapes)
+    model.cuda()
+    tr = Trainer(model, base_lr=3e-3, seed=5)
+    batch = make_batch(4, *shapes, vocab=300, context=3, device="cuda", seed=21)
+    batch["question_indices"] = (batch["question_indices"] % 499 + 1) * batch["question_mask"]
+    monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
+    monkeypatch.setenv("SAM_DECODE_FUSED", "1")
+
+    def decode():
+        model.eval()
+        model.decode_cache = True
+        bd = clone_batch(batch)
+        with torch.no_grad():
+            return model(bd)["textvqa_scores"].float().cpu()
+    for _ in range(3):
+        tr.step(clone_batch(batch))
+    first = decode()
+    ses = next(iter(model._sam_decode_sessions.values()))
+    assert ses.fused
+    for _ in range(3):
+        tr.step(clone_batch(batch))                       # (model.train() again, three more graph replays)
+    second = decode()
+    assert next(iter(model._sam_decode_sessions.values())) is ses
+    monkeypatch.setenv("SAM_DECODE_FUSED", "0")
+    model.__dict__.pop("_sam_decode_sessions", None)
+    want = decode()
+    live = want > -9000
+    err = ((second - want).abs()[live].max() / want[live].abs().max()).item()
+    moved = ((first - want).abs()[live].max() / want[live].abs().max()).item()
+    assert err < 6e-3 and moved > 5 * err, (err, moved)
+
+
 def test_greedy_decode_steps_rejects_what_it_is_not_built_for():
     from sam_textvqa_amd import ops
     from sam_textvqa_amd._capi import SamHipError
