@@ -77,7 +77,20 @@ int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stri
  * the decoder rows only.  Same arithmetic per row as sam_attn_fwd (the results are bit-identical to a full pass over the same values). */
 int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
                      int H, int head_dim, float scale, void* out_dec, void* stream);
-/* autograd of sam_attn_fwd: dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
+/* training forward: sam_attn_fwd plus out_lo bf16 [B*N, H*64] = bf16(out_exact - bf16(out_exact)), the rounding residual of the output.  The one-pass
+ * backward takes delta = rowsum(dO * O) from out + out_lo (exact to 2^-17; the bf16 output alone costs 3e-3 of max in dQ / dK), which is what lets it
+ * compute every score once instead of running a row pass for delta first.  Replaces sam/sa_m4c.py:563-598 as sam_attn_fwd does. */
+int sam_attn_fwd_train(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                       int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, void* out_lo, float* lse2,
+                       uint32_t* keep, void* stream);
+/* autograd of sam/sa_m4c.py:563-598 in ONE pass (N <= sam_attn_bwd_fused_max_n() = 192 keys; SAM_ERR_UNSUPPORTED beyond, use sam_attn_bwd): one workgroup
+ * per (batch, head) stages Q, K, dO once (block-scaled fp16), computes S, P, dP and dS once per score and uses them for dK, dV (in registers) and dQ
+ * (through an LDS exchange of dS).  out / out_lo: the forward's output and residual (sam_attn_fwd_train); keep: its dropout bits (NULL when p_drop = 0). */
+int sam_attn_bwd_fused(const void* dout, const void* qkv, const void* out, const void* out_lo, const float* lse2, const uint32_t* allow,
+                       int64_t allow_stride_b, int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim,
+                       float scale, float p_drop, void* dqkv, void* stream);
+int sam_attn_bwd_fused_max_n(void);
+/* autograd of sam_attn_fwd, two-kernel form (any N <= 384): dout bf16 [B*N,H*64] -> dqkv bf16 [B*N,3*H*64]; delta_ws f32 [B,H,N] scratch */
 int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow, int64_t allow_stride_b,
                  int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim, float scale, float p_drop,
                  void* dqkv, float* delta_ws, void* stream);

@@ -30,6 +30,9 @@ SIGNATURES = {
     "sam_attn_fwd_rows": [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp],
     "sam_attn_bwd": [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp],
     "sam_attn_words_per_row": [_i],
+    "sam_attn_fwd_train": [_vp, _vp, _i64, _i64, _i, _i, _i, _i, _f, _f, _u64, _u64, _vp, _vp, _vp, _vp, _vp],
+    "sam_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp],
+    "sam_attn_bwd_fused_max_n": [],
     "sam_mask_bits_prefix_lm": [_vp, _i, _i, _i, _i, _vp, _vp],
     "sam_mask_bits_from_additive": [_vp, _i, _i, _i, _vp, _vp],
     "sam_mask_bits_spatial": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _u, _vp, _vp],
@@ -78,7 +81,7 @@ SIGNATURES = {
     "sam_ge_u8": [_vp, _i64, _i64, _vp, _vp],
     "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_attn_bwd_fused_max_n", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
 RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes"}
 
 _lib = None

@@ -509,7 +509,11 @@ class EncoderLayerFn(Function):
             return outs[0]
         ctx.coarse = False
         qkv = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
-        ctxv, lse2, keep = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0])
+        fused_bwd = x.shape[0] // batch <= ops.attn_bwd_fused_max_n()
+        if fused_bwd:       # the one-pass attention backward takes delta from the output and its rounding residual
+            ctxv, lse2, keep, ctx_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0], want_residual=True)
+        else:
+            (ctxv, lse2, keep), ctx_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0]), None
         z1 = ops.gemm(ctxv, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x, p_drop=p_hid,
                       seed=seeds[1][0], offset=seeds[1][1])
         a, mean1, rstd1 = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
@@ -518,7 +522,7 @@ class EncoderLayerFn(Function):
         z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a, p_drop=p_hid,
                       seed=seeds[2][0], offset=seeds[2][1])
         y, mean2, rstd2 = ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)
-        ctx.save_for_backward(x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow)
+        ctx.save_for_backward(x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow, ctx_lo)
         return y
 
     @staticmethod
@@ -546,7 +550,7 @@ class EncoderLayerFn(Function):
                                                      ctx.p_attn, p_hid, [v for sd in seeds for v in sd], bool(ctx.needs_input_grad[0]), acc)
                 region_done(getattr(layer, "_sam_region_id", None))
             return (dx if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
-        x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow = ctx.saved_tensors
+        x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow, ctx_lo = ctx.saved_tensors
         wqkv, _, dwqkv, dbqkv = _fused_qkv(att)
         if dy.dtype != BF16 or not dy.is_contiguous():
             dy = dy.to(BF16).contiguous()
@@ -564,7 +568,7 @@ class EncoderLayerFn(Function):
         wgrads.append((dy1, ctxv, so.dense.weight.grad, None))
         dctx = ops.gemm(dy1, _w(so.dense.weight), b_kcontig=False)
         # ---- attention core + fused QKV projection
-        dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn)
+        dqkv = ops.attn_bwd(dctx, qkv, lse2, allow, keep, ctx.batch, att.num_attention_heads, ctx.scale, ctx.p_attn, out=ctxv, out_lo=ctx_lo)
         wgrads.append((dqkv, x, dwqkv, dbqkv))
         if defer:
             DeferredWgrads.add(layer, wgrads, acc)
@@ -617,16 +621,19 @@ class AttentionFn(Function):
     def forward(ctx, qkv, allow, batch, heads, scale, p_drop):
         qkv = qkv.contiguous()
         seed = dropout_clock.next()
-        out, lse2, keep = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed)
-        ctx.save_for_backward(qkv, lse2, keep, allow)
+        if qkv.shape[0] // batch <= ops.attn_bwd_fused_max_n():
+            out, lse2, keep, out_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed, want_residual=True)
+        else:
+            (out, lse2, keep), out_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed), None
+        ctx.save_for_backward(qkv, lse2, keep, allow, out, out_lo)
         ctx.cfg = (batch, heads, scale, p_drop)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        qkv, lse2, keep, allow = ctx.saved_tensors
+        qkv, lse2, keep, allow, out, out_lo = ctx.saved_tensors
         batch, heads, scale, p_drop = ctx.cfg
-        return ops.attn_bwd(dout.to(BF16).contiguous(), qkv, lse2, allow, keep, batch, heads, scale, p_drop), None, None, None, None, None
+        return ops.attn_bwd(dout.to(BF16).contiguous(), qkv, lse2, allow, keep, batch, heads, scale, p_drop, out=out, out_lo=out_lo), None, None, None, None, None
 
 
 # ------------------------------------------------------------------------------------------------ pointer net / loss

@@ -12,18 +12,11 @@
 // registers, P feeds the PV MFMA as its B operand with NO cross-lane movement, and V (stored
 // row-major [key][d] in LDS) is consumed through ds_read_b64_tr_b16.  The contraction index of
 // every second-stage MFMA is enumerated as k(g,e) = 32*s + 16*(e>>2) + 4*g + (e&3).
-#include "common.h"
+#include "attn_common.h"
+
+using namespace attn;
 
 namespace {
-
-constexpr int HD = 64;            // head dim
-constexpr int ROW_BYTES = HD * 2;  // one LDS tile row
-constexpr float LOG2E = 1.4426950408889634f;
-
-// byte offset of 16-byte chunk `ch` (0..7) of tile row `row`; the XOR keeps both ds_read_b128 row
-// reads (16 rows x same chunk) and ds_read_b64_tr_b16 column reads (8 rows x same 32-B block)
-// conflict-free ("LDS layouts").
-__device__ __forceinline__ int tile_off(int row, int ch) { return row * ROW_BYTES + ((ch ^ (((row >> 1) & 3) << 1)) << 4); }
 
 // stage rows [0,n_valid) of a [*, ld] bf16 matrix slice (64 columns) into an LDS tile of npad rows
 __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* base, int64_t ld, int n_valid, int npad, int tid) {
@@ -35,30 +28,8 @@ __device__ __forceinline__ void stage_tile(unsigned char* lds, const bf16_t* bas
   }
 }
 
-// decode: rows [0, n_split) come from `base`, rows [n_split, n_valid) from `base2` (row r at base2 + (r - n_split) * ld)
-__device__ __forceinline__ void stage_tile2(unsigned char* lds, const bf16_t* base, const bf16_t* base2, int n_split, int64_t ld, int n_valid, int npad, int tid) {
-  for (int c = tid; c < npad * 8; c += blockDim.x) {
-    const int row = c >> 3, ch = c & 7;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row < n_valid) v = *reinterpret_cast<const uint4*>((row < n_split ? base + (int64_t)row * ld : base2 + (int64_t)(row - n_split) * ld) + ch * 8);
-    *reinterpret_cast<uint4*>(lds + tile_off(row, ch)) = v;
-  }
-}
-
-__device__ __forceinline__ bf16x8 lds_row_frag(const unsigned char* tile, int row, int ch) {
-  return *reinterpret_cast<const bf16x8*>(tile + tile_off(row, ch));
-}
-// transposed fragment: lane (i,g) gets tile[32*s + 16*(e>>2) + 4*g + (e&3)][16*dt + i], e = 0..7
-__device__ __forceinline__ bf16x8 lds_col_frag(const unsigned char* tile, int s, int dt, int i, int g) {
-  const int row = 32 * s + 4 * g + (i >> 2);
-  const unsigned char* p = tile + tile_off(row, 2 * dt + ((i & 3) >> 1)) + (i & 1) * 8;
-  return cat4(lds_read_tr16(p), lds_read_tr16(p + 16 * ROW_BYTES));  // row+16 has the same swizzle
-}
-
-// Second-stage operands (P, dS) are fp32 values that must enter a bf16 MFMA.  A single bf16 rounding
-// costs ~2.5e-3*max in the worst output element (measured); splitting v = hi + lo (two MFMAs on the same
-// accumulator) brings the operand error to 2^-17, leaving only the bf16 rounding of the stored result.
-// The kernels are HBM-bound, the extra MFMAs are hidden.
+// Second-stage operands of the two-kernel backward (long sequences): v = hi + lo bf16 pairs (two MFMAs on the same accumulator); the
+// forward and the one-pass backward use fp16 instead (attn_common.h).
 __device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& lo) {
   typedef __attribute__((ext_vector_type(4))) unsigned u4;
   u4 h, l;
@@ -71,158 +42,153 @@ __device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& 
   lo = __builtin_bit_cast(bf16x8, l);
 }
 
-struct AttnArgs {
-  const bf16_t* qkv;    // [B*N, 3*H*64]  q | k | v
-  const bf16_t* dout;   // [B*N, H*64]    (bwd only)
-  bf16_t* out_w;        // fwd output
-  bf16_t* dqkv;         // [B*N, 3*H*64]  (bwd output)
-  const uint32_t* allow;  // [B, Hm, N, NW]
-  int64_t allow_sb, allow_sh;
-  uint32_t* keep_w;       // [B, H, N, NW] fwd writes (dropout only)
-  const uint32_t* keep;   // bwd reads (nullptr = everything kept)
-  float* lse2_w;          // [B, H, N] fwd writes: log2-domain logsumexp of scale*s (+inf for dead rows)
-  const float* lse2;
-  float* delta;           // [B, H, N] bwd workspace: sum_k P*dP per query row
-  int B, N, H, NW, nkt, q_begin;   // q_begin: first query row to compute (forward only; rounded down to a 16-row tile)
-  // decoding (attn_fwd_kernel<NKT, true>): the q|k|v rows of the n_dec = N - n_enc decoder tokens live in their own compact buffer
-  // qkv_dec [B * n_dec, 3*H*64] (written by this step's QKV projection, no copy into the cache), the encoder rows in `qkv` as ever;
-  // only decoder rows are written, compactly, to out_dec [B * n_dec, H*64]
-  const bf16_t* qkv_dec;
-  bf16_t* out_dec;
-  int n_enc;
-  float scale, scale_log2, p_drop, inv_keep;
-  unsigned thr16, seed_lo, seed_hi, off_lo, off_hi;
-  const unsigned long long* rng_state;
-};
-
 // --------------------------------------------------------------------------------------------
 // forward
 // --------------------------------------------------------------------------------------------
-// Long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU: those launches use
-// 8 waves per block (two per SIMD) instead of 4 -- with one wave per SIMD nothing hides the MFMA -> softmax -> MFMA dependency chain
-// (stress shape, B = 32: forward 88.7 us, backward 252 us at 4 waves).  The forward also runs 8 waves at 12 key tiles (two blocks = 16 waves per CU
-// instead of three blocks = 12: 34.1 -> 31.2 us with dropout at B = 64); the dQ kernel does not gain from it (77 -> 80 us) and stays at 4.
-template <int NKT, bool DEC = false>
-__global__ __launch_bounds__(NKT <= 8 ? 256 : 512, NKT <= 8 ? 3 : 2) void attn_fwd_kernel(AttnArgs a) {
+// One workgroup = one (batch, head).  K (bf16, as stored) and V (converted to block-scaled fp16) live in LDS; each wave owns 16-query
+// strips.  Per score the VALU does: mask as the MFMA's C operand (-inf where the allow bit is clear: 2 ops), running max (1/2), one
+// fma + exp2, the row sum, half a v_cvt_pk_f16_f32 -- and with dropout a packed 16-bit threshold test on the fp16 pairs, the keep-bit
+// word and the counter hash.  Rounds 1-3 spent 23 VALU per score here (hi/lo bf16 split, select-based masks, 32-bit multiplies in the
+// hash); this is ~13 with dropout, ~6 without.
+constexpr int fwd_waves_per_eu(int nkt, int nt) {     // blocks per CU by LDS (2 tiles of nkt * 2 KB) x waves per block / 4 SIMDs, rounded up
+  return nkt >= 16 ? 2 : nkt == 12 ? (nt == 512 ? 4 : nt == 384 ? 5 : 3) : nkt == 2 ? 2 : 4;
+}
+template <int NKT, bool DEC, bool DROP, int NT>
+__global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel(AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int NPAD = NKT * 16;
+  constexpr int NPAD = NKT * 16, NCH = NPAD * 8, PER = NCH / NT, NWV = NT / 64;
+  static_assert(NCH % NT == 0, "tile chunks must divide evenly over the block");
   unsigned char* Ks = smem;
   unsigned char* Vs = smem + NPAD * ROW_BYTES;
+  unsigned* red = reinterpret_cast<unsigned*>(Vs + NPAD * ROW_BYTES);      // [NWV]
   const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int N = a.N, Dm = a.H * HD;
   const int64_t ld = 3 * (int64_t)Dm;
   const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
   const bf16_t* dbase = DEC ? a.qkv_dec + (int64_t)b * (N - a.n_enc) * ld + h * HD : nullptr;
-  if (DEC) {
-    stage_tile2(Ks, qbase + Dm, dbase + Dm, a.n_enc, ld, N, NPAD, tid);
-    stage_tile2(Vs, qbase + 2 * Dm, dbase + 2 * Dm, a.n_enc, ld, N, NPAD, tid);
-  } else {
-    stage_tile(Ks, qbase + Dm, ld, N, NPAD, tid);
-    stage_tile(Vs, qbase + 2 * Dm, ld, N, NPAD, tid);
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+
+  // ---- stage K as it is and V as block-scaled fp16; every load is unconditional at a clamped row (no branch in front of a load)
+  uint4 vreg[PER];
+  unsigned vmax = 0;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = tid + j * NT, row = c >> 3, ch = c & 7, rc = row < N ? row : N - 1;
+    const bf16_t* src = (DEC && rc >= a.n_enc) ? dbase + (int64_t)(rc - a.n_enc) * ld : qbase + (int64_t)rc * ld;
+    uint4 kv = *reinterpret_cast<const uint4*>(src + Dm + ch * 8);
+    uint4 vv = *reinterpret_cast<const uint4*>(src + 2 * Dm + ch * 8);
+    if (row >= N) { kv = make_uint4(0, 0, 0, 0); vv = make_uint4(0, 0, 0, 0); }
+    *reinterpret_cast<uint4*>(Ks + tile_off(row, ch)) = kv;
+    vreg[j] = vv;
+    vmax = absmax_acc4(vmax, vv);
+  }
+  vmax = wave_max_u32(absmax_fold(vmax));
+  if (lane == 0) red[wave] = vmax;
+  __syncthreads();
+  unsigned bmax = 0;
+#pragma unroll
+  for (int w = 0; w < NWV; ++w) bmax = red[w] > bmax ? red[w] : bmax;
+  const int cv = scale_c_of(bmax);
+  const unsigned csub = csub_of(cv);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int c = tid + j * NT;
+    *reinterpret_cast<uint4*>(Vs + tile_off(c >> 3, c & 7)) = bf2h_pk4(vreg[j], csub);
   }
   __syncthreads();
 
-  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
   unsigned seed_lo = a.seed_lo, seed_hi = a.seed_hi, off_lo = a.off_lo, off_hi = a.off_hi;
-  if (a.thr16) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
-  const int nwaves = blockDim.x >> 6;
-  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += nwaves) {
+  if (DROP) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  const unsigned thr2 = ((a.thr16 ^ 0x8000u) & 0xffffu) * 0x00010001u;
+  const unsigned nibmask = 0x000F000Fu << (4 * g);
+  const float o_unscale = ldexpf(a.inv_keep, cv - 112);          // V16 * 2^(cv-112) = V; the 2^P_SHIFT of P cancels against the row sum
+  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += NWV) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
     bf16x8 qf[2];
     const bf16_t* qrow = (DEC && qc >= a.n_enc) ? dbase + (int64_t)(qc - a.n_enc) * ld : qbase + (int64_t)qc * ld;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
-    unsigned aw[NKT / 2];
+    unsigned naw[NKT / 2];        // inverted allow words, pre-shifted so that this lane's four keys of a tile sit at bits 0..3 / 16..19
     const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
 #pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) aw[w] = ap[w];
+    for (int w = 0; w < NKT / 2; ++w) naw[w] = ~ap[w] >> (4 * g);
 
+    // scores with the mask as the accumulator's initial value: S = -inf wherever the allow bit is clear
     f32x4 s[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      f32x4 acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        acc[r] = __int_as_float(__builtin_amdgcn_sbfe((int)naw[t >> 1], (unsigned)((t & 1) * 16 + r), 1u) & (int)0xff800000u);
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc, 0, 0, 0);
       s[t] = acc;
     }
-    // mask (bit test only), scale into the log2 domain, row max
     float mx = -INFINITY;
 #pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      const unsigned nib = (aw[t >> 1] >> ((t & 1) * 16 + 4 * g)) & 0xFu;
+    for (int t = 0; t < NKT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float v = ((nib >> r) & 1u) ? s[t][r] * a.scale_log2 : -INFINITY;
-        s[t][r] = v;
-        mx = fmaxf(mx, v);
-      }
-    }
+      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
     mx = xgroup_max(mx);
     const bool alive = mx > -INFINITY;  // reference: fully masked rows give exactly 0 (sa_m4c.py:574-584)
-    const float mref = alive ? mx : 0.f;
+    const float bias = (float)P_SHIFT - (alive ? mx : 0.f) * a.scale_log2;
     float sum = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(s[t][r] - mref);
+        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2, bias));     // 2^14 * exp(scale * s - max); -inf -> 0
         s[t][r] = p;
         sum += p;
       }
     sum = xgroup_sum(sum);
-    // PV, one 32-key slab (two score tiles) at a time so that only the fp32 probabilities stay live: dropout
-    // (sa_m4c.py:588: after the row zeroing, before PV), hi/lo bf16 split, then 2 x 4 MFMAs into the 4 d-tile accumulators
-    const float inv = alive ? a.inv_keep / sum : 0.f;
+    const unsigned rk = DROP ? attn_row_key((unsigned)(bh * N + qc), off_lo, off_hi, seed_lo, seed_hi) : 0u;
+    // PV, one 32-key slab (two score tiles) at a time: fp16 pairs, dropout (sa_m4c.py:588: after the row zeroing, before PV) as a packed
+    // mask, one MFMA per 16-column block of V
+    const float inv = alive ? o_unscale * __builtin_amdgcn_rcpf(sum) : 0.f;
     f32x4 o[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NKT / 2; ++w) {
-      float v8[8] = {s[2 * w][0], s[2 * w][1], s[2 * w][2], s[2 * w][3], s[2 * w + 1][0], s[2 * w + 1][1], s[2 * w + 1][2], s[2 * w + 1][3]};
-      if (a.thr16 != 0) {
-        const u32x4 rn = dropout_bits128((unsigned)(bh * N + qc), (unsigned)(w * 4 + g), off_lo, off_hi, seed_lo, seed_hi);
-        const unsigned rr[4] = {rn.x, rn.y, rn.z, rn.w};
-        unsigned bits = 0;
+      typedef __attribute__((ext_vector_type(4))) unsigned u4;
+      u4 pk;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const unsigned r16 = (rr[e >> 1] >> ((e & 1) * 16)) & 0xffffu;
-          const bool kept = r16 >= a.thr16;
-          if (!kept) v8[e] = 0.f;
-          bits |= (kept ? 1u : 0u) << ((e >> 2) * 16 + 4 * g + (e & 3));
-        }
-        bits = xgroup_or(bits);
+      for (int j = 0; j < 4; ++j) pk[j] = pack_f16x2(s[2 * w + (j >> 1)][2 * (j & 1)], s[2 * w + (j >> 1)][2 * (j & 1) + 1]);
+      if (DROP) {
+        const u32x4 rn = attn_dropout_bits(rk, (unsigned)(w * 4 + g));
+        const unsigned dm0 = drop_mask16x2(rn.x, thr2), dm1 = drop_mask16x2(rn.y, thr2), dm2 = drop_mask16x2(rn.z, thr2), dm3 = drop_mask16x2(rn.w, thr2);
+        pk[0] &= ~dm0; pk[1] &= ~dm1; pk[2] &= ~dm2; pk[3] &= ~dm3;
+        // keep word of this query row: bit (e>>2)*16 + 4g + (e&3) for the lane's e-th key of the slab (e = 2j / 2j+1 = low / high half of pair j)
+        const unsigned x01 = (dm0 & 0x00020001u) | (dm1 & 0x00080004u), x23 = (dm2 & 0x00020001u) | (dm3 & 0x00080004u);
+        const unsigned dropped = (((x01 | (x01 >> 16)) & 0xFu) | (((x23 | (x23 >> 16)) & 0xFu) << 16)) << (4 * g);
+        const unsigned bits = xgroup_or(nibmask & ~dropped);
         if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
       }
-      bf16x8 pa, pl;
-      split_pack8(v8, pa, pl);
+      const f16x8 pa = __builtin_bit_cast(f16x8, pk);
       bf16x8 vt[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vt[dt] = lds_col_frag(Vs, w, dt, i, g);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pa, o[dt], 0, 0, 0);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[dt], pl, o[dt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting all V fragments costs 96 VGPRs and a wave of occupancy
+      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(vt[dt]), pa, o[dt], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting every V fragment and hash costs a wave of occupancy
     }
-    if (DEC) {
-      if (q < N && q >= a.n_enc) {
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-          uint2 ov = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
-          *reinterpret_cast<uint2*>(a.out_dec + ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm + h * HD + 16 * dt + 4 * g) = ov;
-        }
-      }
-      continue;
-    }
-    if (q < N) {
+    const bool wr = DEC ? (q < N && q >= a.n_enc) : (q < N);
+    if (wr) {
+      bf16_t* dst = DEC ? a.out_dec + ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm + h * HD + 4 * g : a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 4 * g;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) {
-        uint2 ov = make_uint2(pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv), pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv));
-        *reinterpret_cast<uint2*>(a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 16 * dt + 4 * g) = ov;
+        const float o0 = o[dt][0] * inv, o1 = o[dt][1] * inv, o2 = o[dt][2] * inv, o3 = o[dt][3] * inv;
+        const uint2 hi = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
+        *reinterpret_cast<uint2*>(dst + 16 * dt) = hi;
+        if (!DEC && a.out_lo_w)
+          *reinterpret_cast<uint2*>(a.out_lo_w + ((int64_t)b * N + q) * Dm + h * HD + 4 * g + 16 * dt) =
+              make_uint2(pack_bf16x2(o0 - bf_lo(hi.x), o1 - bf_hi(hi.x)), pack_bf16x2(o2 - bf_lo(hi.y), o3 - bf_hi(hi.y)));
       }
+      if (!DEC && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx * a.scale_log2 + __builtin_amdgcn_logf(sum) - (float)P_SHIFT : INFINITY;
     }
-    if (q < N && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx + __builtin_amdgcn_logf(sum) : INFINITY;
   }
 }
 
@@ -516,6 +482,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkdv_kernel(AttnArgs a) {
   }
 }
 
+}  // namespace
+
+namespace attn {
+
 int pick_nkt(int N) {
   const int need = (N + 15) / 16;
   const int opts[] = {2, 4, 8, 12, 16, 24};
@@ -528,6 +498,7 @@ int fill_common(AttnArgs& a, int B, int N, int H, int head_dim, float scale, flo
   SAM_REQUIRE(head_dim == HD, "sam_attn: head_dim must be 64 (got %d)", head_dim);
   SAM_REQUIRE(B > 0 && N > 0 && H > 0, "sam_attn: empty problem B=%d N=%d H=%d", B, N, H);
   SAM_REQUIRE(p_drop >= 0.f && p_drop < 1.f, "sam_attn: p_drop=%f out of [0,1)", p_drop);
+  SAM_REQUIRE(scale > 0.f, "sam_attn: scale=%f must be positive", scale);
   const int nkt = pick_nkt(N);
   SAM_REQUIRE(nkt > 0, "sam_attn: N=%d exceeds the 384-key single-pass limit", N);
   a.B = B; a.N = N; a.H = H; a.nkt = nkt; a.NW = nkt / 2;
@@ -538,30 +509,56 @@ int fill_common(AttnArgs& a, int B, int N, int H, int head_dim, float scale, flo
   return SAM_OK;
 }
 
-template <int NKT>
-int launch_fwd(const AttnArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES;
+}  // namespace attn
+
+namespace {
+
+// threads per block: long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU, and
+// run 8 waves (two per SIMD); 12 key tiles (N = 182) run SAM_ATTN_FWD_NT threads (default 512; 384 = two strips per wave, three blocks per CU)
+template <int NKT, bool DEC, bool DROP, int NT>
+int launch_fwd_nt(const AttnArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES + 64;
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT, DEC, DROP, NT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     once = true;
   }
-  attn_fwd_kernel<NKT><<<dim3(a.B * a.H), dim3(NKT <= 8 ? 256 : 512), lds, st>>>(a);
+  attn_fwd_kernel<NKT, DEC, DROP, NT><<<dim3(a.B * a.H), dim3(NT), lds, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
 
-template <int NKT>
-int launch_dec(const AttnArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES;
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
+int fwd_nt12() {
+  static int nt = -1;
+  if (nt < 0) {
+    const char* e = getenv("SAM_ATTN_FWD_NT");
+    nt = e ? atoi(e) : 512;
+    if (nt != 256 && nt != 384 && nt != 512) nt = 512;
   }
-  attn_fwd_kernel<NKT, true><<<dim3(a.B * a.H), dim3(NKT <= 8 ? 256 : 512), lds, st>>>(a);
-  SAM_LAUNCH_CHECK();
-  return SAM_OK;
+  return nt;
+}
+
+template <int NKT, bool DEC, bool DROP>
+int launch_fwd_d(const AttnArgs& a, hipStream_t st) {
+  if (NKT == 12) {
+    switch (fwd_nt12()) {
+      case 256: return launch_fwd_nt<12, DEC, DROP, 256>(a, st);
+      case 384: return launch_fwd_nt<12, DEC, DROP, 384>(a, st);
+      default: return launch_fwd_nt<12, DEC, DROP, 512>(a, st);
+    }
+  }
+  return launch_fwd_nt<NKT, DEC, DROP, (NKT <= 2 ? 128 : NKT <= 8 ? 256 : 512)>(a, st);
+}
+
+template <bool DEC>
+int launch_fwd_any(const AttnArgs& a, hipStream_t st) {
+  const bool drop = !DEC && a.thr16 != 0;
+#define SAM_FWD_CASE(K) case K: return drop ? launch_fwd_d<K, DEC, !DEC>(a, st) : launch_fwd_d<K, DEC, false>(a, st);
+  switch (a.nkt) {
+    SAM_FWD_CASE(2) SAM_FWD_CASE(4) SAM_FWD_CASE(8) SAM_FWD_CASE(12) SAM_FWD_CASE(16) SAM_FWD_CASE(24)
+  }
+#undef SAM_FWD_CASE
+  return SAM_ERR_UNSUPPORTED;
 }
 
 }  // namespace
@@ -575,16 +572,7 @@ extern "C" int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const 
   SAM_REQUIRE(n_dec > 0 && n_dec < N, "sam_attn_fwd_dec: n_dec=%d outside (0,%d)", n_dec, N);
   a.qkv = (const bf16_t*)qkv_enc; a.qkv_dec = (const bf16_t*)qkv_dec; a.out_dec = (bf16_t*)out_dec; a.n_enc = N - n_dec;
   a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h; a.q_begin = N - n_dec;
-  hipStream_t st = (hipStream_t)stream;
-  switch (a.nkt) {
-    case 2: return launch_dec<2>(a, st);
-    case 4: return launch_dec<4>(a, st);
-    case 8: return launch_dec<8>(a, st);
-    case 12: return launch_dec<12>(a, st);
-    case 16: return launch_dec<16>(a, st);
-    case 24: return launch_dec<24>(a, st);
-  }
-  return SAM_ERR_UNSUPPORTED;
+  return launch_fwd_any<true>(a, (hipStream_t)stream);
 }
 
 extern "C" int sam_attn_words_per_row(int N) {
@@ -593,43 +581,37 @@ extern "C" int sam_attn_words_per_row(int N) {
 }
 
 static int attn_fwd_impl(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
-                         int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, int q_begin, void* out, float* lse2,
-                         uint32_t* keep, void* stream);
-
-extern "C" int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
-                            int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
-                            uint32_t* keep, void* stream) {
-  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, p_drop, seed, offset, 0, out, lse2, keep, stream);
-}
-
-extern "C" int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
-                                 int head_dim, float scale, int q_begin, void* out, float* lse2, void* stream) {
-  SAM_REQUIRE(q_begin >= 0 && q_begin < N, "sam_attn_fwd_rows: q_begin=%d outside [0,%d)", q_begin, N);
-  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, 0.f, 0, 0, q_begin, out, lse2, nullptr, stream);
-}
-
-static int attn_fwd_impl(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
-                         int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, int q_begin, void* out, float* lse2,
+                         int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, int q_begin, void* out, void* out_lo, float* lse2,
                          uint32_t* keep, void* stream) {
   AttnArgs a = {};
   int rc = fill_common(a, B, N, H, head_dim, scale, p_drop);
   if (rc) return rc;
   SAM_REQUIRE(qkv && allow && out && lse2, "sam_attn_fwd: null pointer");
   SAM_REQUIRE(a.thr16 == 0 || keep, "sam_attn_fwd: dropout needs a keep-bits buffer");
-  a.qkv = (const bf16_t*)qkv; a.out_w = (bf16_t*)out; a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h;
+  a.qkv = (const bf16_t*)qkv; a.out_w = (bf16_t*)out; a.out_lo_w = (bf16_t*)out_lo; a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h;
   a.lse2_w = lse2; a.keep_w = keep; a.q_begin = q_begin;
   a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.off_lo = (unsigned)offset; a.off_hi = (unsigned)(offset >> 32);
   a.rng_state = sam_get_rng_state();
-  hipStream_t st = (hipStream_t)stream;
-  switch (a.nkt) {
-    case 2: return launch_fwd<2>(a, st);
-    case 4: return launch_fwd<4>(a, st);
-    case 8: return launch_fwd<8>(a, st);
-    case 12: return launch_fwd<12>(a, st);
-    case 16: return launch_fwd<16>(a, st);
-    case 24: return launch_fwd<24>(a, st);
-  }
-  return SAM_ERR_UNSUPPORTED;
+  return launch_fwd_any<false>(a, (hipStream_t)stream);
+}
+
+extern "C" int sam_attn_fwd(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                            int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, float* lse2,
+                            uint32_t* keep, void* stream) {
+  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, p_drop, seed, offset, 0, out, nullptr, lse2, keep, stream);
+}
+
+extern "C" int sam_attn_fwd_train(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                                  int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, void* out_lo, float* lse2,
+                                  uint32_t* keep, void* stream) {
+  SAM_REQUIRE(out_lo, "sam_attn_fwd_train: out_lo is null (use sam_attn_fwd when the residual is not wanted)");
+  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, p_drop, seed, offset, 0, out, out_lo, lse2, keep, stream);
+}
+
+extern "C" int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
+                                 int head_dim, float scale, int q_begin, void* out, float* lse2, void* stream) {
+  SAM_REQUIRE(q_begin >= 0 && q_begin < N, "sam_attn_fwd_rows: q_begin=%d outside [0,%d)", q_begin, N);
+  return attn_fwd_impl(qkv, allow, allow_stride_b, allow_stride_h, B, N, H, head_dim, scale, 0.f, 0, 0, q_begin, out, nullptr, lse2, nullptr, stream);
 }
 
 extern "C" int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uint32_t* allow,

@@ -17,6 +17,7 @@
 
 #include <tuple>
 #include <string>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -121,6 +122,45 @@ std::tuple<Tensor, Tensor, Tensor> attn_fwd(const Tensor& qkv, const Tensor& all
                   (uint32_t*)p(keep), cur_stream()),
      "sam_attn_fwd");
   return {out, lse2, keep.defined() ? keep : at::empty({0}, allow.options())};
+}
+
+// training forward: also returns the bf16 rounding residual of the output (what the one-pass backward takes delta from)
+std::tuple<Tensor, Tensor, Tensor, Tensor> attn_fwd_train(const Tensor& qkv, const Tensor& allow, int64_t batch, int64_t heads, double scale, double p_drop, int64_t seed,
+                                                          int64_t offset) {
+  need2d(qkv, "qkv"); need(allow, at::kInt, "allow");
+  TORCH_CHECK(allow.dim() == 4 && allow.is_contiguous(), "allow must be a contiguous int32 [B, H|1, N, NW] tensor");
+  const int64_t rows = qkv.size(0), d_model = qkv.size(1) / 3, n = rows / batch;
+  Tensor out = at::empty({rows, d_model}, qkv.options());
+  Tensor out_lo = at::empty({rows, d_model}, qkv.options());
+  Tensor lse2 = at::empty({batch, heads, n}, qkv.options().dtype(at::kFloat));
+  Tensor keep = p_drop > 0 ? at::empty({batch, heads, n, allow.size(3)}, allow.options()) : Tensor();
+  ok(sam_attn_fwd_train(qkv.data_ptr(), (const uint32_t*)allow.data_ptr(), allow.stride(0), allow.size(1) == 1 ? 0 : allow.stride(1), (int)batch, (int)n, (int)heads,
+                        (int)(d_model / heads), (float)scale, (float)p_drop, (uint64_t)seed, (uint64_t)offset, out.data_ptr(), out_lo.data_ptr(), (float*)lse2.data_ptr(),
+                        (uint32_t*)p(keep), cur_stream()),
+     "sam_attn_fwd_train");
+  return {out, lse2, keep.defined() ? keep : at::empty({0}, allow.options()), out_lo};
+}
+
+static bool fused_attn_bwd_enabled(int64_t n) {
+  static int e = -1;
+  if (e < 0) {
+    const char* s = getenv("SAM_ATTN_BWD_FUSED");
+    e = (s && s[0] == '0') ? 0 : 1;
+  }
+  return e && n <= sam_attn_bwd_fused_max_n();
+}
+
+Tensor attn_bwd_fused(const Tensor& dout, const Tensor& qkv, const Tensor& out, const Tensor& out_lo, const Tensor& lse2, const Tensor& allow, const Tensor& keep,
+                      int64_t batch, int64_t heads, double scale, double p_drop) {
+  need2d(dout, "dout"); need2d(qkv, "qkv"); need2d(out, "out"); need2d(out_lo, "out_lo"); need(lse2, at::kFloat, "lse2"); need(allow, at::kInt, "allow");
+  const int64_t rows = qkv.size(0), d_model = qkv.size(1) / 3, n = rows / batch;
+  Tensor dqkv = at::empty_like(qkv);
+  const bool has_keep = keep.defined() && keep.numel() > 0;
+  ok(sam_attn_bwd_fused(dout.data_ptr(), qkv.data_ptr(), out.data_ptr(), out_lo.data_ptr(), (const float*)lse2.data_ptr(), (const uint32_t*)allow.data_ptr(),
+                        allow.stride(0), allow.size(1) == 1 ? 0 : allow.stride(1), has_keep ? (const uint32_t*)keep.data_ptr() : nullptr, (int)batch, (int)n, (int)heads,
+                        (int)(d_model / heads), (float)scale, (float)p_drop, dqkv.data_ptr(), cur_stream()),
+     "sam_attn_bwd_fused");
+  return dqkv;
 }
 
 Tensor attn_bwd(const Tensor& dout, const Tensor& qkv, const Tensor& lse2, const Tensor& allow, const Tensor& keep, int64_t batch, int64_t heads, double scale,
@@ -358,7 +398,8 @@ void step_advance(const optional<Tensor>& rng_state, int64_t offset_stride, Tens
 // params: wqkv bf16 [3D,D], bqkv f32 [3D], wo bf16 [D,D], bo f32, ln1_w, ln1_b, w1 bf16 [I,D], b1 f32, w2 bf16 [D,I], b2 f32, ln2_w, ln2_b
 enum { P_WQKV, P_BQKV, P_WO, P_BO, P_LN1W, P_LN1B, P_W1, P_B1, P_W2, P_B2, P_LN2W, P_LN2B, P_COUNT };
 // saved: x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2
-enum { S_X, S_QKV, S_CTX, S_LSE, S_KEEP, S_Z1, S_MEAN1, S_RSTD1, S_A, S_PRE, S_H, S_Z2, S_MEAN2, S_RSTD2, S_COUNT };
+// (+ ctx_lo, the output residual of the attention forward, last: empty when the sequence is too long for the one-pass attention backward)
+enum { S_X, S_QKV, S_CTX, S_LSE, S_KEEP, S_Z1, S_MEAN1, S_RSTD1, S_A, S_PRE, S_H, S_Z2, S_MEAN2, S_RSTD2, S_CTXLO, S_COUNT };
 
 std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::TensorList params, int64_t batch, int64_t heads, double scale, double p_attn,
                                       double p_hid, at::IntArrayRef seeds, double eps1, double eps2) {
@@ -368,7 +409,9 @@ std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::
   GemmOpt o;
   o.epilogue = SAM_EPI_BIAS; o.bias = &params[P_BQKV];
   Tensor qkv = gemm(x, params[P_WQKV], true, true, o);                                                   // sa_m4c.py:554-560
-  auto [ctx, lse2, keep] = attn_fwd(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]);          // :563-598
+  Tensor ctx, lse2, keep, ctx_lo;
+  if (fused_attn_bwd_enabled(x.size(0) / batch)) std::tie(ctx, lse2, keep, ctx_lo) = attn_fwd_train(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]);      // :563-598
+  else { std::tie(ctx, lse2, keep) = attn_fwd(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]); ctx_lo = at::empty({0}, x.options()); }
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_BO]; o.residual = &x; o.p_drop = (float)p_hid; o.seed = seeds[2]; o.offset = seeds[3];
   Tensor z1 = gemm(ctx, params[P_WO], true, true, o);                                                     // BertSelfOutput via :653
   auto [a, mean1, rstd1] = ln_fwd(z1, params[P_LN1W], params[P_LN1B], eps1);
@@ -378,7 +421,7 @@ std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_B2]; o.residual = &a; o.p_drop = (float)p_hid; o.seed = seeds[4]; o.offset = seeds[5];
   Tensor z2 = gemm(h, params[P_W2], true, true, o);                                                       // BertOutput via :680
   auto [y, mean2, rstd2] = ln_fwd(z2, params[P_LN2W], params[P_LN2B], eps2);
-  return {y, x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2};
+  return {y, x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, ctx_lo};
 }
 
 // grads: same order as params, fp32 views into the flat gradient buffer (accumulated in place).  Returns dx (undefined-size-0 when !need_dx).
@@ -403,7 +446,8 @@ static std::vector<Tensor> encoder_layer_bwd_impl(const Tensor& dy_in, at::Tenso
   auto [dz1, dy1] = ln_bwd(da, z1, saved[S_MEAN1], saved[S_RSTD1], params[P_LN1W], grads[P_LN1W], grads[P_LN1B], &grads[P_BO], true, p_hid, seeds[2], seeds[3], accumulate, true);
   Tensor dctx = gemm(dy1, params[P_WO], true, false, GemmOpt());
   // ---- attention core + fused QKV projection
-  Tensor dqkv = attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
+  Tensor dqkv = saved[S_CTXLO].numel() ? attn_bwd_fused(dctx, qkv, ctx, saved[S_CTXLO], lse2, allow, keep, batch, heads, scale, p_attn)
+                                       : attn_bwd(dctx, qkv, lse2, allow, keep, batch, heads, scale, p_attn);
   const Tensor dw2 = grads[P_W2], dw1 = grads[P_W1], db1 = grads[P_B1], dwo = grads[P_WO], dwqkv = grads[P_WQKV], dbqkv = grads[P_BQKV];
   // defer_wgrad: the four weight gradients are left to the caller, which runs them for several layers in ONE grouped launch (TextBert's three
   // 1280-row layers: 3 x 38 us of launches that cannot fill the chip -> one); the gradient operands come back with dx
@@ -462,6 +506,8 @@ TORCH_LIBRARY(sam_hip, m) {
         "bool b_kcontig, bool out_f32) -> (Tensor, Tensor)");
   m.def("spatial_attn_fwd(Tensor qkv, Tensor allow, int batch, int heads, float scale, float p_drop, int seed, int offset) -> (Tensor, Tensor, Tensor)");
   m.def("spatial_attn_bwd(Tensor dout, Tensor qkv, Tensor lse2, Tensor allow, Tensor keep, int batch, int heads, float scale, float p_drop) -> Tensor");
+  m.def("spatial_attn_fwd_train(Tensor qkv, Tensor allow, int batch, int heads, float scale, float p_drop, int seed, int offset) -> (Tensor, Tensor, Tensor, Tensor)");
+  m.def("spatial_attn_bwd_fused(Tensor dout, Tensor qkv, Tensor out, Tensor out_lo, Tensor lse2, Tensor allow, Tensor keep, int batch, int heads, float scale, float p_drop) -> Tensor");
   m.def("layernorm_fwd(Tensor x, Tensor gamma, Tensor beta, float eps) -> (Tensor, Tensor, Tensor)");
   m.def("layernorm_bwd(Tensor dy, Tensor x, Tensor mean, Tensor rstd, Tensor gamma) -> (Tensor, Tensor, Tensor)");
   m.def("set_ln_defer(bool on) -> ()");
@@ -499,6 +545,8 @@ TORCH_LIBRARY_IMPL(sam_hip, CUDA, m) {      // (the ROCm backend registers under
   m.impl("linear", linear_op);
   m.impl("spatial_attn_fwd", attn_fwd);
   m.impl("spatial_attn_bwd", attn_bwd);
+  m.impl("spatial_attn_fwd_train", attn_fwd_train);
+  m.impl("spatial_attn_bwd_fused", attn_bwd_fused);
   m.impl("layernorm_fwd", layernorm_fwd_op);
   m.impl("layernorm_bwd", layernorm_bwd_op);
   m.impl("encoder_layer_fwd", encoder_layer_fwd);

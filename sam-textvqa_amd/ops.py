@@ -2,6 +2,8 @@
 
 Every function takes/returns CUDA(ROCm) tensors, allocates outputs with torch, passes raw device
 pointers + the current HIP stream to libsam_hip.so and never synchronises."""
+import os
+
 import torch
 
 from . import _capi as capi
@@ -125,21 +127,27 @@ def mask_bits_spatial(base_bits, adj, n_txt, n_heads, quadrants):
 
 
 # ----------------------------------------------------------------------------- attention
-def attn_fwd(qkv, allow, batch, n_heads, scale, p_drop=0.0, seed=0, offset=0):
-    """qkv bf16 [B*N, 3*H*64]; allow uint32 [B, H or 1, N, NW] -> (out bf16 [B*N, H*64], lse2 f32 [B,H,N], keep or None)."""
+def attn_fwd(qkv, allow, batch, n_heads, scale, p_drop=0.0, seed=0, offset=0, want_residual=False):
+    """qkv bf16 [B*N, 3*H*64]; allow uint32 [B, H or 1, N, NW] -> (out bf16 [B*N, H*64], lse2 f32 [B,H,N], keep or None);
+    want_residual=True (training: sam_attn_fwd_train) appends out_lo, the bf16 rounding residual of `out` the one-pass backward takes delta from."""
     _chk(qkv, BF16, "qkv"); _chk(allow, torch.int32, "allow")
     rows, three_d = qkv.shape
     n = rows // batch
     d_model = three_d // 3
     out = torch.empty((rows, d_model), dtype=BF16, device=qkv.device)
+    out_lo = torch.empty_like(out) if want_residual else None
     lse2 = torch.empty((batch, n_heads, n), dtype=torch.float32, device=qkv.device)
     keep = torch.empty((batch, n_heads, n, allow.shape[-1]), dtype=torch.int32, device=qkv.device) if p_drop > 0 else None
     sh = 0 if allow.shape[1] == 1 else allow.stride(1)
     nw = allow.shape[-1]
-    alg_bytes = batch * (4 * n * d_model * 2 + n_heads * n * nw * 4 * (2 if p_drop > 0 else 1) + n_heads * n * 4)
+    alg_bytes = batch * ((5 if want_residual else 4) * n * d_model * 2 + n_heads * n * nw * 4 * (2 if p_drop > 0 else 1) + n_heads * n * 4)
+    meta = dict(kernel="attn_fwd", bytes=alg_bytes, flops=4.0 * batch * n * n * d_model, shape=(batch, n, n_heads))
+    if want_residual:
+        capi.call("sam_attn_fwd_train", capi.ptr(qkv), capi.ptr(allow), allow.stride(0), sh, batch, n, n_heads, d_model // n_heads,
+                  float(scale), float(p_drop), int(seed), int(offset), capi.ptr(out), capi.ptr(out_lo), capi.ptr(lse2), capi.ptr(keep), capi.stream_handle(), meta=meta)
+        return out, lse2, keep, out_lo
     capi.call("sam_attn_fwd", capi.ptr(qkv), capi.ptr(allow), allow.stride(0), sh, batch, n, n_heads, d_model // n_heads,
-              float(scale), float(p_drop), int(seed), int(offset), capi.ptr(out), capi.ptr(lse2), capi.ptr(keep), capi.stream_handle(),
-              meta=dict(kernel="attn_fwd", bytes=alg_bytes, flops=4.0 * batch * n * n * d_model, shape=(batch, n, n_heads)))
+              float(scale), float(p_drop), int(seed), int(offset), capi.ptr(out), capi.ptr(lse2), capi.ptr(keep), capi.stream_handle(), meta=meta)
     return out, lse2, keep
 
 
@@ -184,20 +192,39 @@ def beam_step(fixed, ocr, n_samples, beam, seqs, cum, done, eos, t=0, ctl=None, 
               capi.ptr(ctl), capi.ptr(cum), capi.ptr(done), capi.ptr(seqs), capi.ptr(prev_pos), capi.stream_handle())
 
 
-def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0):
-    """-> dqkv bf16 [B*N, 3*H*64]."""
+_FUSED_MAX_N = None
+
+
+def attn_bwd_fused_max_n():
+    global _FUSED_MAX_N
+    if _FUSED_MAX_N is None:
+        _FUSED_MAX_N = int(capi.call("sam_attn_bwd_fused_max_n"))
+    return _FUSED_MAX_N
+
+
+def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0, out=None, out_lo=None):
+    """-> dqkv bf16 [B*N, 3*H*64].  With the forward's output and residual (attn_fwd(..., want_residual=True)) and N <= 192 this is the one-pass
+    kernel (sam_attn_bwd_fused); otherwise the two-kernel form (sam_attn_bwd: a dQ pass that also produces delta, then dK / dV)."""
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv")
     rows, three_d = qkv.shape
     n = rows // batch
     d_model = three_d // 3
     dqkv = torch.empty_like(qkv)
-    delta = torch.empty((batch, n_heads, n), dtype=torch.float32, device=qkv.device)
     sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    bits_bytes = n_heads * n * (allow.shape[-1] * 4 * (2 if keep is not None else 1) + 8)
+    if out is not None and out_lo is not None and n <= attn_bwd_fused_max_n() and os.environ.get("SAM_ATTN_BWD_FUSED", "1") != "0":
+        _chk(out, BF16, "out"); _chk(out_lo, BF16, "out_lo")
+        capi.call("sam_attn_bwd_fused", capi.ptr(dout), capi.ptr(qkv), capi.ptr(out), capi.ptr(out_lo), capi.ptr(lse2), capi.ptr(allow), allow.stride(0), sh,
+                  capi.ptr(keep), batch, n, n_heads, d_model // n_heads, float(scale), float(p_drop), capi.ptr(dqkv), capi.stream_handle(),
+                  meta=dict(kernel="attn_bwd(fused)", flops=10.0 * batch * n * n * d_model, shape=(batch, n, n_heads),
+                            bytes=batch * (10 * n * d_model * 2 + bits_bytes)))        # reads q,k,v,dO,O,O_lo; writes dq,dk,dv
+        return dqkv
+    delta = torch.empty((batch, n_heads, n), dtype=torch.float32, device=qkv.device)
     capi.call("sam_attn_bwd", capi.ptr(dout), capi.ptr(qkv), capi.ptr(lse2), capi.ptr(allow), allow.stride(0), sh,
               capi.ptr(keep), batch, n, n_heads, d_model // n_heads, float(scale), float(p_drop), capi.ptr(dqkv), capi.ptr(delta),
               capi.stream_handle(),
               meta=dict(kernel="attn_bwd(dq+dkdv)", flops=10.0 * batch * n * n * d_model, shape=(batch, n, n_heads),
-                        bytes=batch * (8 * n * d_model * 2 + n_heads * n * (allow.shape[-1] * 4 * (2 if keep is not None else 1) + 8))))
+                        bytes=batch * (8 * n * d_model * 2 + bits_bytes)))
     return dqkv
 
 

@@ -370,3 +370,122 @@ def test_dropout_streams_are_independent_across_rows_columns_offsets_and_seeds()
     assert torch.equal((z != 0).float(), h0)
     # attention dropout and hidden dropout under the SAME (seed, offset) are different streams
     assert abs(_agree(keep(3, 9)[0, 0, :, :182].reshape(-1)[: 182 * 182].cpu(), h0[:182, :182].reshape(-1).cpu()) - indep) < 0.01
+
+
+# ------------------------------------------------------------------------------------------------ one-pass backward (sam_attn_bwd_fused)
+@pytest.mark.parametrize("shape,spatial", [((3, 20, 100, 50, 12), True), ((3, 20, 100, 50, 12), False), ((4, 20, 0, 0, 0), False), ((2, 5, 30, 20, 7), True),
+                                           ((2, 8, 60, 40, 12), True)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_attention_fused_backward(shape, spatial, p_drop):
+    """the training pair sam_attn_fwd_train / sam_attn_bwd_fused (every score computed once, delta from the output and its residual) against the
+    fp32 oracle at the kernel bound, and against the two-kernel backward on the same saved tensors"""
+    ops = _ops()
+    dev = "cuda"
+    B, T, n_obj, n_ocr, n_dec = shape
+    H, hd = 12, 64
+    if n_obj + n_ocr == 0:
+        rng = np.random.RandomState(3)
+        kvm = torch.from_numpy(C.pad_mask([int(rng.randint(1, T + 1)) for _ in range(B)], T))
+        pr = dict(B=B, T=T, n_oo=0, n_dec=0, N=T, H=H, key_valid=kvm, adj=None)
+    else:
+        pr = make_problem(*shape, seed=2)
+    N = pr["N"]
+    assert N <= ops.attn_bwd_fused_max_n()
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).to(dev), pr["n_dec"])
+    if spatial:
+        allow_bits = ops.mask_bits_spatial(base, pr["adj"].to(dev), pr["T"], H, (1, 2))
+        allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], (1, 2), H)
+    else:
+        allow_bits = base
+        allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], None, (), H)
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * N, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B * N, H * hd, generator=g).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(hd)
+    out, lse2, keep_bits, out_lo = ops.attn_fwd(qkv.to(dev), allow_bits, B, H, scale, p_drop, seed=1234, offset=7, want_residual=True)
+    out_plain, lse_plain, keep_plain = ops.attn_fwd(qkv.to(dev), allow_bits, B, H, scale, p_drop, seed=1234, offset=7)
+    assert torch.equal(out, out_plain) and torch.equal(lse2, lse_plain)           # the residual is an extra output, nothing else changes
+    keep, inv_keep = None, 1.0
+    if p_drop > 0:
+        assert torch.equal(keep_bits, keep_plain)
+        keep = unpack_bits(keep_bits, N)
+        inv_keep = 1.0 / (1.0 - round(p_drop * 65536) / 65536.0)
+    qkv_ref = qkv.float().requires_grad_(True)
+    ref_out, _ = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
+    # out + out_lo carries the output to ~2^-16: an order of magnitude inside the bf16 quantum
+    both = out.float().cpu() + out_lo.float().cpu()
+    err_hi = (out.float().cpu() - ref_out.detach()).abs().max().item()
+    err_both = (both - ref_out.detach()).abs().max().item()
+    assert err_both <= 1.2e-3 * ref_out.abs().max().item(), (err_both, err_hi)
+    (ref_out * dout.float()).sum().backward()
+    dqkv = ops.attn_bwd(dout.to(dev), qkv.to(dev), lse2, allow_bits, keep_bits, B, H, scale, p_drop, out=out, out_lo=out_lo)
+    e = assert_close_bf16(dqkv, qkv_ref.grad, name="fused attn dqkv")
+    dqkv2 = ops.attn_bwd(dout.to(dev), qkv.to(dev), lse2, allow_bits, keep_bits, B, H, scale, p_drop)          # two-kernel form
+    e2 = assert_close_bf16(dqkv2, qkv_ref.grad, name="two-kernel attn dqkv")
+    print("PARITY fused attention backward N=%d p=%.1f: %.2e of max (two-kernel form %.2e)" % (N, p_drop, e, e2))
+    # rows of fully padded samples / masked keys: exact zeros in dK, dV of keys nobody may see
+    dead_keys = ~allow.any(-2)                                                    # [B, H, N]
+    dk = dqkv.float().cpu().view(B, N, 3, H, hd)[:, :, 1].permute(0, 2, 1, 3)
+    dv = dqkv.float().cpu().view(B, N, 3, H, hd)[:, :, 2].permute(0, 2, 1, 3)
+    assert (dk[dead_keys] == 0).all() and (dv[dead_keys] == 0).all()
+
+
+@pytest.mark.parametrize("T", [1, 17, 33, 100, 129, 192])
+def test_attention_fused_backward_sequence_length_edges(T):
+    """every key-tile template of the one-pass backward (2, 4, 8, 12 tiles) at and just past its boundaries; key-padding mask, dropout on"""
+    ops = _ops()
+    B, H, hd = 3, 12, 64
+    valid = [T, max(1, T // 2), 1]
+    kvm = torch.from_numpy(C.pad_mask(valid, T))
+    base = ops.mask_bits_prefix_lm(kvm.to(torch.uint8).cuda(), 0)
+    allow = O.allow_mask(kvm, T, 0, 0, None, (), H)
+    g = torch.Generator().manual_seed(9)
+    qkv = (torch.randn(B * T, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16)
+    dout = torch.randn(B * T, H * hd, generator=g).to(torch.bfloat16)
+    scale = 1.0 / math.sqrt(hd)
+    out, lse2, keep_bits, out_lo = ops.attn_fwd(qkv.cuda(), base, B, H, scale, 0.1, seed=77, offset=3, want_residual=True)
+    keep = unpack_bits(keep_bits, T)
+    inv_keep = 1.0 / (1.0 - round(0.1 * 65536) / 65536.0)
+    qkv_ref = qkv.float().requires_grad_(True)
+    ref_out, _ = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
+    assert_close_bf16(out, ref_out, name="attn out T=%d" % T)
+    (ref_out * dout.float()).sum().backward()
+    dqkv = ops.attn_bwd(dout.cuda(), qkv.cuda(), lse2, base, keep_bits, B, H, scale, 0.1, out=out, out_lo=out_lo)
+    assert_close_bf16(dqkv, qkv_ref.grad, name="fused attn dqkv T=%d" % T)
+
+
+@pytest.mark.parametrize("qs,ks,vs,ds", [(1.0, 1.0, 1e-6, 1.0), (1.0, 1.0, 1.0, 1e-9), (1e-3, 1e3, 300.0, 1e5), (0.05, 30.0, 1e4, 1e-4), (1.0, 1.0, 0.0, 1.0), (1.0, 1.0, 1.0, 0.0)])
+def test_attention_fp16_block_scaling_is_scale_free(qs, ks, vs, ds):
+    """the fp16 second stage must not care about magnitudes: q, k, v and dO at 1e-9 .. 1e5 of their usual scale (gradients of a loss that is
+    normalised differently, values before a tiny or huge output projection) meet the same bound as O(1) data, through the block scaling of
+    csrc/attn_common.h; all-zero V and dO tiles are handled (scale exponent clamps)"""
+    ops = _ops()
+    B, H, hd, N = 2, 12, 64, 182
+    pr = make_problem(B, 20, 100, 50, 12, seed=11)
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).cuda(), pr["n_dec"])
+    bits = ops.mask_bits_spatial(base, pr["adj"].cuda(), pr["T"], H, (1, 2))
+    allow = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], (1, 2), H)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B * N, 3, H * hd, generator=g) * 1.5
+    x[:, 0] *= qs; x[:, 1] *= ks; x[:, 2] *= vs
+    qkv = x.reshape(B * N, -1).to(torch.bfloat16)
+    dout = (torch.randn(B * N, H * hd, generator=g) * ds).to(torch.bfloat16)
+    scale = 0.125
+    out, lse2, keep_bits, out_lo = ops.attn_fwd(qkv.cuda(), bits, B, H, scale, 0.1, seed=5, offset=1, want_residual=True)
+    keep = unpack_bits(keep_bits, N)
+    inv_keep = 1.0 / (1.0 - round(0.1 * 65536) / 65536.0)
+    qkv_ref = qkv.float().requires_grad_(True)
+    ref_out, _ = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
+    (ref_out * dout.float()).sum().backward()
+    if vs > 0:
+        assert_close_bf16(out, ref_out, name="attn out (scaled inputs)")
+    else:
+        assert (out == 0).all()
+    dqkv = ops.attn_bwd(dout.cuda(), qkv.cuda(), lse2, bits, keep_bits, B, H, scale, 0.1, out=out, out_lo=out_lo)
+    gref = qkv_ref.grad.view(B * N, 3, H * hd)
+    got = dqkv.float().cpu().view(B * N, 3, H * hd)
+    for j, nm in enumerate(("dq", "dk", "dv")):      # per operand: their magnitudes differ by the scale factors
+        if gref[:, j].abs().max() == 0:
+            assert (got[:, j] == 0).all(), nm
+        else:
+            assert_close_bf16(got[:, j], gref[:, j], name="%s (scaled inputs)" % nm)

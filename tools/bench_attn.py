@@ -26,10 +26,17 @@ for tag, B, shape in (("c3", 64, SHAPES["c3"]), ("stress", 32, SHAPES["stress"])
     dout = torch.randn(B * N, 768, device="cuda").to(torch.bfloat16)
     for name, allow in (("spatial", sp), ("plain", base)):
         for p in (0.0, 0.1):
-            out, lse2, keep = ops.attn_fwd(qkv, allow, B, H, 0.125, p, 1, 1)
+            out, lse2, keep, out_lo = ops.attn_fwd(qkv, allow, B, H, 0.125, p, 1, 1, want_residual=True)
             nw = allow.shape[-1]
             fb = B * (4 * N * 768 * 2 + H * N * nw * 4 * (2 if p else 1) + H * N * 4)
             bb = B * (8 * N * 768 * 2 + H * N * (nw * 4 * (2 if p else 1) + 8))
             uf = t(lambda: ops.attn_fwd(qkv, allow, B, H, 0.125, p, 1, 1))
+            ut = t(lambda: ops.attn_fwd(qkv, allow, B, H, 0.125, p, 1, 1, want_residual=True))
             ub = t(lambda: ops.attn_bwd(dout, qkv, lse2, allow, keep, B, H, 0.125, p))
-            print("%-6s %-8s p=%.1f  fwd %6.1f us %6.0f GB/s (%.1f%% of 8 TB/s)   bwd %6.1f us %6.0f GB/s (%.1f%%)" % (tag, name, p, uf, fb / uf / 1e3, fb / uf / 1e3 / 80, ub, bb / ub / 1e3, bb / ub / 1e3 / 80))
+            line = "%-6s %-8s p=%.1f  fwd %6.1f us %6.0f GB/s (%.1f%% of 8 TB/s)   fwd+residual %6.1f us   bwd(2 kernels) %6.1f us %6.0f GB/s (%.1f%%)" % (
+                tag, name, p, uf, fb / uf / 1e3, fb / uf / 1e3 / 80, ut, ub, bb / ub / 1e3, bb / ub / 1e3 / 80)
+            if N <= ops.attn_bwd_fused_max_n():
+                b1 = B * (10 * N * 768 * 2 + H * N * (nw * 4 * (2 if p else 1) + 8))
+                u1 = t(lambda: ops.attn_bwd(dout, qkv, lse2, allow, keep, B, H, 0.125, p, out=out, out_lo=out_lo))
+                line += "   bwd(fused) %6.1f us %6.0f GB/s (%.1f%%)" % (u1, b1 / u1 / 1e3, b1 / u1 / 1e3 / 80)
+            print(line, flush=True)
