@@ -68,6 +68,23 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
   const bf16_t* dbase = DEC ? a.qkv_dec + (int64_t)b * (N - a.n_enc) * ld + h * HD : nullptr;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
 
+  // the first strip's query rows and allow words are requested before the tiles are staged, every later strip's while the previous one computes:
+  // with one or two strips per wave a load issued at the top of its own strip is a full memory latency nobody else covers
+  const int mt0 = (a.q_begin >> 4) + wave;
+  bf16x8 qf_n[2];
+  unsigned naw_n[NKT / 2];        // inverted allow words, pre-shifted so that this lane's four keys of a tile sit at bits 0..3 / 16..19
+  auto load_strip = [&](int mt) {
+    int q = mt * 16 + i;
+    q = q < N ? q : N - 1;
+    const bf16_t* qrow = (DEC && q >= a.n_enc) ? dbase + (int64_t)(q - a.n_enc) * ld : qbase + (int64_t)q * ld;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf_n[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
+    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)q * a.NW;
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) naw_n[w] = ap[w];
+  };
+  load_strip(mt0);
+
   // ---- stage K as it is and V as block-scaled fp16; every load is unconditional at a clamped row (no branch in front of a load)
   uint4 vreg[PER];
   unsigned vmax = 0;
@@ -102,16 +119,13 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
   const unsigned thr2 = ((a.thr16 ^ 0x8000u) & 0xffffu) * 0x00010001u;
   const unsigned nibmask = 0x000F000Fu << (4 * g);
   const float o_unscale = ldexpf(a.inv_keep, cv - 112);          // V16 * 2^(cv-112) = V; the 2^P_SHIFT of P cancels against the row sum
-  for (int mt = (a.q_begin >> 4) + wave; mt * 16 < N; mt += NWV) {
+  for (int mt = mt0; mt * 16 < N; mt += NWV) {
     const int q = mt * 16 + i, qc = q < N ? q : N - 1;
-    bf16x8 qf[2];
-    const bf16_t* qrow = (DEC && qc >= a.n_enc) ? dbase + (int64_t)(qc - a.n_enc) * ld : qbase + (int64_t)qc * ld;
+    bf16x8 qf[2] = {qf_n[0], qf_n[1]};
+    unsigned naw[NKT / 2];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
-    unsigned naw[NKT / 2];        // inverted allow words, pre-shifted so that this lane's four keys of a tile sit at bits 0..3 / 16..19
-    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
-#pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) naw[w] = ~ap[w] >> (4 * g);
+    for (int w = 0; w < NKT / 2; ++w) naw[w] = ~naw_n[w] >> (4 * g);
+    load_strip(mt + NWV);          // (clamped to the last row when there is no next strip)
 
     // scores with the mask as the accumulator's initial value: S = -inf wherever the allow bit is clear
     f32x4 s[NKT];
@@ -135,18 +149,22 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
     const bool alive = mx > -INFINITY;  // reference: fully masked rows give exactly 0 (sa_m4c.py:574-584)
     const float bias = (float)P_SHIFT - (alive ? mx : 0.f) * a.scale_log2;
     float sum = 0.f;
+    unsigned pk[2 * NKT];               // P * 2^14 as fp16 pairs: (keys 4g, 4g+1) and (4g+2, 4g+3) of every tile
 #pragma unroll
-    for (int t = 0; t < NKT; ++t)
+    for (int t = 0; t < NKT; ++t) {
+      float p[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2, bias));     // 2^14 * exp(scale * s - max); -inf -> 0
-        s[t][r] = p;
-        sum += p;
+        p[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2, bias));     // 2^14 * exp(scale * s - max); -inf -> 0
+        sum += p[r];
       }
+      pk[2 * t] = pack_f16x2(p[0], p[1]);
+      pk[2 * t + 1] = pack_f16x2(p[2], p[3]);
+    }
     sum = xgroup_sum(sum);
     const unsigned rk = DROP ? attn_row_key((unsigned)(bh * N + qc), off_lo, off_hi, seed_lo, seed_hi) : 0u;
-    // PV, one 32-key slab (two score tiles) at a time: fp16 pairs, dropout (sa_m4c.py:588: after the row zeroing, before PV) as a packed
-    // mask, one MFMA per 16-column block of V
+    // PV, one 32-key slab (two score tiles) at a time: dropout (sa_m4c.py:588: after the row zeroing, before PV) as a packed mask on the fp16
+    // pairs, one MFMA per 16-column block of V
     const float inv = alive ? o_unscale * __builtin_amdgcn_rcpf(sum) : 0.f;
     f32x4 o[4];
 #pragma unroll
@@ -154,20 +172,18 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
 #pragma unroll
     for (int w = 0; w < NKT / 2; ++w) {
       typedef __attribute__((ext_vector_type(4))) unsigned u4;
-      u4 pk;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) pk[j] = pack_f16x2(s[2 * w + (j >> 1)][2 * (j & 1)], s[2 * w + (j >> 1)][2 * (j & 1) + 1]);
+      u4 pw = {pk[4 * w], pk[4 * w + 1], pk[4 * w + 2], pk[4 * w + 3]};
       if (DROP) {
         const u32x4 rn = attn_dropout_bits(rk, (unsigned)(w * 4 + g));
         const unsigned dm0 = drop_mask16x2(rn.x, thr2), dm1 = drop_mask16x2(rn.y, thr2), dm2 = drop_mask16x2(rn.z, thr2), dm3 = drop_mask16x2(rn.w, thr2);
-        pk[0] &= ~dm0; pk[1] &= ~dm1; pk[2] &= ~dm2; pk[3] &= ~dm3;
+        pw[0] &= ~dm0; pw[1] &= ~dm1; pw[2] &= ~dm2; pw[3] &= ~dm3;
         // keep word of this query row: bit (e>>2)*16 + 4g + (e&3) for the lane's e-th key of the slab (e = 2j / 2j+1 = low / high half of pair j)
         const unsigned x01 = (dm0 & 0x00020001u) | (dm1 & 0x00080004u), x23 = (dm2 & 0x00020001u) | (dm3 & 0x00080004u);
         const unsigned dropped = (((x01 | (x01 >> 16)) & 0xFu) | (((x23 | (x23 >> 16)) & 0xFu) << 16)) << (4 * g);
         const unsigned bits = xgroup_or(nibmask & ~dropped);
         if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
       }
-      const f16x8 pa = __builtin_bit_cast(f16x8, pk);
+      const f16x8 pa = __builtin_bit_cast(f16x8, pw);
       bf16x8 vt[4];
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt) vt[dt] = lds_col_frag(Vs, w, dt, i, g);
@@ -175,20 +191,30 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
       for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(vt[dt]), pa, o[dt], 0, 0, 0);
       __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting every V fragment and hash costs a wave of occupancy
     }
+    // epilogue, 16 bytes per store: v_permlane16_swap pairs the 4-column fragments of two neighbouring lane groups, lane (i, g) then owns the
+    // eight consecutive columns 32 jp + 16 (g & 1) + 8 (g >> 1) .. +7 of query row i
     const bool wr = DEC ? (q < N && q >= a.n_enc) : (q < N);
-    if (wr) {
-      bf16_t* dst = DEC ? a.out_dec + ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm + h * HD + 4 * g : a.out_w + ((int64_t)b * N + q) * Dm + h * HD + 4 * g;
+    const int64_t orow = DEC ? ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm : ((int64_t)b * N + q) * Dm;
+    const int ocol = h * HD + 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        const float o0 = o[dt][0] * inv, o1 = o[dt][1] * inv, o2 = o[dt][2] * inv, o3 = o[dt][3] * inv;
-        const uint2 hi = make_uint2(pack_bf16x2(o0, o1), pack_bf16x2(o2, o3));
-        *reinterpret_cast<uint2*>(dst + 16 * dt) = hi;
-        if (!DEC && a.out_lo_w)
-          *reinterpret_cast<uint2*>(a.out_lo_w + ((int64_t)b * N + q) * Dm + h * HD + 4 * g + 16 * dt) =
-              make_uint2(pack_bf16x2(o0 - bf_lo(hi.x), o1 - bf_hi(hi.x)), pack_bf16x2(o2 - bf_lo(hi.y), o3 - bf_hi(hi.y)));
+    for (int jp = 0; jp < 2; ++jp) {
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[2 * jp][r]), __float_as_uint(o[2 * jp + 1][r]), false, false);
+        v[r] = __uint_as_float(sw[0]) * inv;
+        v[4 + r] = __uint_as_float(sw[1]) * inv;
       }
-      if (!DEC && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx * a.scale_log2 + __builtin_amdgcn_logf(sum) - (float)P_SHIFT : INFINITY;
+      const uint4 hi = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      if (wr) {
+        *reinterpret_cast<uint4*>((DEC ? a.out_dec : a.out_w) + orow + ocol + 32 * jp) = hi;
+        if (!DEC && a.out_lo_w)
+          *reinterpret_cast<uint4*>(a.out_lo_w + orow + ocol + 32 * jp) =
+              make_uint4(pack_bf16x2(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x)), pack_bf16x2(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y)),
+                         pack_bf16x2(v[4] - bf_lo(hi.z), v[5] - bf_hi(hi.z)), pack_bf16x2(v[6] - bf_lo(hi.w), v[7] - bf_hi(hi.w)));
+      }
     }
+    if (!DEC && wr && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx * a.scale_log2 + __builtin_amdgcn_logf(sum) - (float)P_SHIFT : INFINITY;
   }
 }
 

@@ -10,7 +10,9 @@ for d in ("pmc_attn1","pmc_attn2"):
     agg=collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(R+"/gpurun_out/%s/a_counter_collection.csv"%d)):
         if "attn_" in r["Kernel_Name"]:
-            agg[r["Kernel_Name"].split("(")[0][-40:]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kn = r["Kernel_Name"]
+            kn = kn[kn.index("attn_"):].split("(")[0][:44]
+            agg[kn][r["Counter_Name"]].append(float(r["Counter_Value"]))
     for kn,c in agg.items():
         print(kn, {n: "%.3g"%(sum(v)/len(v)) for n,v in c.items()})
 PY
