@@ -45,32 +45,39 @@ def train_gflop(shape, n_layers, vocab, D=768):
     return 3.0 * fwd / 1e9
 
 
-def profile_step(trainer, batch):
-    """one instrumented step: HIP events around every C-ABI launch, on the stream the kernels run on"""
+def profile_step(trainer, batch, reps=5):
+    """`reps` instrumented steps: HIP events around every C-ABI launch, on the stream the kernels run on; every launch's time is the MEDIAN of its
+    bracket over the repetitions (SURVEY 8(d) asks for medians; one eager step alone carries the clock ramp of its first launches)"""
     from sam_textvqa_amd import _capi as capi
     from sam_textvqa_amd.synthetic import clone_batch
-    torch.cuda.synchronize()
-    torch.cuda._sleep(int(40e6))     # ~20 ms of GPU spin: the host enqueues the whole step ahead of the GPU, so every
-    # event pair brackets kernel execution only (no host-launch gaps inside the brackets).  What a bracket still contains besides the kernel is the
-    # cost of the bracket itself (the second event's timestamp packet is processed behind the kernel, the kernel's dispatch behind the first): it
-    # is measured here, live, as the elapsed time of EMPTY brackets queued under the same spin, and subtracted from every bracket below
-    # (`event_overhead_us` in the JSON line; without it the 117 us rocprofv3 reports for the dominant kernel read as 132 us)
-    empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
-    for e0, e1 in empty:
-        e0.record()
-        e1.record()
-    capi.profiler = []
-    trainer._eager_step(clone_batch(batch))       # the per-kernel route (no graph replay, no coarse C++ ops): one event pair per launch
-    torch.cuda.synchronize()
-    recs, capi.profiler = capi.profiler, None
-    overhead_ms = sorted(e0.elapsed_time(e1) for e0, e1 in empty)[len(empty) // 2]
-    agg = {"@event_overhead_us": 1e3 * overhead_ms}
-    for name, meta, e0, e1 in recs:
+    runs, overheads = [], []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        torch.cuda._sleep(int(40e6))     # ~20 ms of GPU spin: the host enqueues the whole step ahead of the GPU, so every
+        # event pair brackets kernel execution only (no host-launch gaps inside the brackets).  What a bracket still contains besides the kernel is the
+        # cost of the bracket itself (the second event's timestamp packet is processed behind the kernel, the kernel's dispatch behind the first): it
+        # is measured here, live, as the elapsed time of EMPTY brackets queued under the same spin, and subtracted from every bracket below
+        # (`event_overhead_us` in the JSON line; without it the 117 us rocprofv3 reports for the dominant kernel read as 132 us)
+        empty = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(32)]
+        for e0, e1 in empty:
+            e0.record()
+            e1.record()
+        capi.profiler = []
+        trainer._eager_step(clone_batch(batch))       # the per-kernel route (no graph replay, no coarse C++ ops): one event pair per launch
+        torch.cuda.synchronize()
+        recs, capi.profiler = capi.profiler, None
+        overheads.append(sorted(e0.elapsed_time(e1) for e0, e1 in empty)[len(empty) // 2])
+        runs.append([(name, meta, e0.elapsed_time(e1)) for name, meta, e0, e1 in recs])
+    overhead_ms = statistics.median(overheads)
+    if any(len(r) != len(runs[0]) for r in runs):     # (cannot happen with static shapes; fall back to the last run rather than mis-align)
+        runs = runs[-1:]
+    agg = {"@event_overhead_us": 1e3 * overhead_ms, "@instrumented_steps": len(runs)}
+    for j, (name, meta, _) in enumerate(runs[0]):
         key = meta.get("kernel", name)
         if key.startswith("gemm<") and meta.get("shape"):
             key += "@M=%d" % meta["shape"][0]             # MMT-size (11648 rows) and TextBert / head-size launches of one symbol are different regimes
         a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
-        dt = max(e0.elapsed_time(e1) - overhead_ms, 0.0)
+        dt = max(statistics.median(r[j][2] for r in runs) - overhead_ms, 0.0)
         a["calls"] += 1
         a["ms"] += dt
         a["flops"] += meta.get("flops", 0.0)
@@ -101,7 +108,7 @@ def pmc_traffic(kernel_key):
         pat8 = re.compile(r"gemm8_kernel<\d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
         sel = [v for k, v in kern.items() if pat.match(k) or pat8.match(k)]
     else:
-        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"],
+        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel"],
                  "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
         sel = [v for k, v in kern.items() if any(k.startswith(n) for n in names)]
     n = sum(v["launches_profiled"] for v in sel)
@@ -130,6 +137,7 @@ def pmc_mfma_util(kernel_key):
 def roofline_from(agg):
     shapes = agg.pop("@shapes", {})
     overhead_us = agg.pop("@event_overhead_us", 0.0)
+    n_instr = agg.pop("@instrumented_steps", 1)
     total_ms = sum(a["ms"] for a in agg.values())
     table = []
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1]["ms"]):
@@ -152,7 +160,7 @@ def roofline_from(agg):
         roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
                     traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
     extra = {}
-    for key in ("attn_fwd", "attn_bwd(dq+dkdv)"):     # the north-star kernel: HBM-bound, reported next to the dominant (GEMM) kernel
+    for key in ("attn_fwd", "attn_bwd(fused)", "attn_bwd(dq+dkdv)"):     # the north-star kernel: HBM-bound, reported next to the dominant (GEMM) kernel
         if key in agg and agg[key]["bytes"]:
             a = agg[key]
             ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
@@ -164,8 +172,9 @@ def roofline_from(agg):
     extra["gemm_by_shape"] = by_shape[:16]
     roof["event_overhead_us"] = round(overhead_us, 2)
     # what was measured HERE and what was read from the tree: the judge's copy of this line must not suggest the counters ran in this process
-    roof["timing_source"] = ("live: HIP events around every launch of one instrumented EAGER step after the timed region (same kernels as the replayed graph, "
-                             "queued under a GPU spin, empty-bracket cost subtracted); rocprofv3 --kernel-trace --stats of the graph-replay run: profiles/*_kernel_stats.csv")
+    roof["timing_source"] = ("live: HIP events around every launch of %d instrumented EAGER steps after the timed region, per-launch MEDIAN over them (same kernels as "
+                             "the replayed graph, queued under a GPU spin, empty-bracket cost subtracted); rocprofv3 --kernel-trace --stats of the graph-replay run: "
+                             "profiles/*_kernel_stats.csv" % n_instr)
     roof["traffic_source"] = ("committed PMC summary %s (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, gfx950 corrections applied); "
                               "NOT collected in this run" % _PMC_TRAFFIC_FILE) if roof.get("traffic") is not None else None
     if "mfma_util_pmc" in roof:
@@ -246,7 +255,7 @@ def eager_rocm_baseline(context, layers, vocab, shape, batch_size, dev, steps=8,
     return dict(unit="samples/s", batch=batch_size, steps=steps, warmup=warmup, kind="port (oracle on the device, eager PyTorch-ROCm)", **res)
 
 
-def quick_train(context, layers, shape, batch_size, vocab, dev, steps=12, warmup=4, seed=77):
+def quick_train(context, layers, shape, batch_size, vocab, dev, steps=12, warmup=4, seed=77, touch_all=False):
     """a short run of the SAME captured training step at another configuration (SURVEY 8(d)'s secondary rows), outside the timed region"""
     from sam_textvqa_amd.synthetic import clone_batch, make_batch
     from sam_textvqa_amd.trainer import Trainer
@@ -255,6 +264,8 @@ def quick_train(context, layers, shape, batch_size, vocab, dev, steps=12, warmup
     batch = make_batch(batch_size, *shape, vocab=vocab, context=context, device=dev, seed=seed)
     for _ in range(warmup):
         trainer.step(clone_batch(batch))
+    if touch_all and trainer.sparse is not None:
+        trainer.sparse[3].fill_(1)           # every word-table row counts as touched: norm and Adam walk all 30522 rows, as after a few hundred steps of real data
     torch.cuda.synchronize()
     staged = trainer.input_buffers() or batch
     t0 = time.perf_counter()
@@ -265,6 +276,8 @@ def quick_train(context, layers, shape, batch_size, vocab, dev, steps=12, warmup
     gf = train_gflop(shape, len(layers), vocab)
     out = dict(batch=batch_size, steps=steps, ms_per_step=round(1e3 * dt / steps, 3), samples_per_s=round(batch_size * steps / dt, 1), train_gflop_per_sample=round(gf, 2),
                mfma_fraction_whole_step=round(batch_size * steps / dt * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4), final_loss=float(loss.item()))
+    if trainer.sparse is not None:
+        out["word_table_rows_touched"] = int(trainer.sparse[3].sum().item())
     del trainer, model
     torch.cuda.empty_cache()
     return out
@@ -377,6 +390,7 @@ def main():
     ap.add_argument("--no-eager-baseline", action="store_true", help="skip the eager PyTorch-ROCm leg (the oracle on the GPU, BASELINE config 2's A/B partner)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--rotate", type=int, default=16, help="distinct synthetic batches whose token ids / masks / targets take turns (1 = replay one batch, as rounds 1-3 did)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (c=5, stress, north-star literal shape, decoding, 1-rank data-parallel step)")
     args = ap.parse_args()
 
@@ -400,26 +414,54 @@ def main():
     trainer = Trainer(model, seed=1234 + rank, use_graph=not args.no_graph, reducer=reducer)      # (N > 1: captured too when the collectives are RCCL's, trainer._dp_capturable)
     trainer.measure_comm = trainer.reducer is not None        # (N > 1, or a 1-rank group under SAM_FORCE_DIST=1)
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
+    # The step's work depends on its input VALUES in one place: the row-sparse word-embedding table (norm + Adam walk only rows that ever received a
+    # gradient).  Replaying one batch would freeze that set at <= B*20 rows; a training run meets new question tokens every step.  So `--rotate` (default 16)
+    # distinct synthetic batches take turns: their small tensors (token ids, masks, previous predictions, targets: everything under 1 MB) are copied
+    # into the captured step's input buffers before each step, inside the timed region; the feature / box / relation blocks (110 MB, values irrelevant
+    # to the work) stay where they are.  `word_table_rows_touched` reports where the set ended up; the secondary row `table fully touched` is the other limit.
+    rot = [batch] + [make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=5000 + 97 * j + rank) for j in range(1, max(1, args.rotate))]
 
-    for _ in range(args.warmup):
-        loss = trainer.step(clone_batch(batch))
+    def small_items(bd):
+        return {k: v.clone() for k, v in bd.items() if torch.is_tensor(v) and v.numel() * v.element_size() < (1 << 20)}
+    rot_small = [small_items(b) for b in rot]
+    rot = rot[:1] if len(rot) == 1 else [None] * len(rot)        # (only the small tensors of the other batches are kept)
+
+    def next_batch(step_idx, base):
+        bd = clone_batch(base)
+        if len(rot) > 1:
+            src = rot_small[step_idx % len(rot)]
+            # in place: `base` is the captured step's own input buffers in graph mode (no staging copy afterwards); one multi-tensor copy per dtype
+            torch._foreach_copy_([bd[k] for k in src], list(src.values()))
+        return bd
+
+    for j in range(args.warmup):
+        loss = trainer.step(next_batch(j, batch) if j else clone_batch(batch))
     torch.cuda.synchronize()
     staged = trainer.input_buffers() if hasattr(trainer, "input_buffers") else None
     if staged is not None:
         # graph mode: the synthetic batch lives in the captured step's own input buffers (where a loader's host-to-device copies would land), as the
         # contract says: inputs resident in HBM when the timed region starts -- no device-to-device staging copy per input per step
         batch = staged
+    # proof that the collectives span `world` devices: every rank contributes a one through the gradient reducer's own group
+    ranks_seen = None
     if parallel.dist.is_initialized():
+        one = torch.ones(1, dtype=torch.float32, device=dev)
+        parallel.dist.all_reduce(one, group=trainer.reducer.group if trainer.reducer is not None else None)
+        ranks_seen = int(round(one.item()))
         parallel.dist.barrier()
     torch.cuda.synchronize()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.step(clone_batch(batch))
+    marks[0].record()
+    for j in range(args.steps):
+        loss = trainer.step(next_batch(args.warmup + j, batch))
+        marks[j + 1].record()
     torch.cuda.synchronize()
     if parallel.dist.is_initialized():
         parallel.dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    step_ms = [marks[j].elapsed_time(marks[j + 1]) for j in range(args.steps)]
     if parallel.dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         parallel.dist.all_reduce(t, op=parallel.dist.ReduceOp.MAX)
@@ -440,6 +482,9 @@ def main():
                                "bf16 MFMA compute, fp32 master weights/Adam" % ((args.context,) + shape + (sum(shape), ",".join(layers), args.vocab)),
                    "global_batch": gb, "per_gpu_batch": args.batch, "seq_len": sum(shape), "parallelism": "dp%d" % world},
         "final_loss": final_loss,
+        "ms_per_step_median": round(statistics.median(step_ms), 3),           # GPU time between per-step events on the launch stream (the value above is the wall-clock mean)
+        "batches_rotated": len(rot),
+        "word_table_rows_touched": int(trainer.sparse[3].sum().item()) if getattr(trainer, "sparse", None) is not None else None,
         "train_gflop_per_sample": round(train_gflop(shape, len(layers), args.vocab), 2),
         "mfma_fraction_whole_step": round(gb * args.steps / dt * train_gflop(shape, len(layers), args.vocab) * 1e9 / (world * PEAK_BF16_TFLOPS * 1e12), 4),
     }
@@ -449,6 +494,9 @@ def main():
         res["gemm_by_shape"] = extra.pop("gemm_by_shape", [])
         res["roofline_attention"] = extra
         res["kernels"] = table
+    if ranks_seen is not None:
+        res["rccl_ranks_seen"] = ranks_seen          # all-reduce of a one per rank over the reducer's group, just before the timed region
+        res["dist_backend"] = parallel.dist.get_backend()
     if trainer is not None and trainer.reducer is not None:
         # GPU time between the end of the backward pass and the end of the gradient exchange, averaged over the timed steps: what the
         # all-reduce costs beyond what the backward hides
@@ -473,6 +521,9 @@ def main():
             torch.cuda.empty_cache()
             sec.append(dict(workload="c=5 (share5 heads, model and data), B=64, same model otherwise (BASELINE configs[2] per GPU)",
                             **quick_train(5, ("n", "n", "s", "s", "s", "s"), SHAPES["c5"], 64, args.vocab, dev)))
+            sec.append(dict(workload="c=3 B=64 with EVERY word-table row already touched (norm + Adam walk all 30522 rows: the regime a long run on real questions converges to; "
+                                     "the headline's rotating synthetic batches sit between this and a single replayed batch)",
+                            **quick_train(args.context, layers, shape, args.batch, args.vocab, dev, touch_all=True)))
             sec.append(dict(workload="stress: 200 obj + 100 OCR + 30 dec + 20 txt = 350 tokens, 12 layers (n,n,s x10), B=32 (BASELINE configs[4] per GPU)",
                             **quick_train(3, ("n", "n") + ("s",) * 10, SHAPES["stress"], 32, args.vocab, dev, steps=8, warmup=3)))
             sec.append(dict(workload="north-star literal: 100 obj + 50 OCR + 12 dec = 162 tokens, the 4 spatial layers only, encoder forward + backward, B=64",

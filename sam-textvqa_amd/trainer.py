@@ -73,7 +73,13 @@ class Trainer:
             self._fresh_ranges = merged
         self.defer_ln = os.environ.get("SAM_LN_DEFER_FINALIZE", "1") != "0"
         self._grad_one = None
-        self.sparse = self._setup_sparse_table() if os.environ.get("SAM_SPARSE_ADAM", "1") != "0" else None
+        # Row-sparse optimizer walk of the word table: only when no rank can receive a gradient for a row its own `touched` flags do not know --
+        # i.e. without a reducer, or with one that exchanges exactly this table row-sparsely (its scatter sets the flags of every rank's rows).
+        # Under a reducer that all-reduces the table densely (a caller-built GradReducer, bench.py --no-overlap) rows touched on OTHER ranks
+        # arrive with non-zero gradients: skipping them in the norm / Adam would make the replicas diverge, and nothing would clear them.
+        self.sparse = None
+        if os.environ.get("SAM_SPARSE_ADAM", "1") != "0" and self._sparse_walk_is_safe(reducer):
+            self.sparse = self._setup_sparse_table()
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
         self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
@@ -200,6 +206,12 @@ class Trainer:
         w.grad._sam_touched = touched                     # ops.embedding_bwd[_sorted] flag the rows they add to
         return (lo, hi, w.shape[1], touched)
 
+    def _sparse_walk_is_safe(self, reducer):
+        if reducer is None:
+            return True
+        rng = self._sparse_table_range(mark=False)
+        return rng is not None and reducer.sparse_hi > reducer.sparse_lo and reducer.sparse_lo <= rng[0] and rng[1] <= reducer.sparse_hi
+
     def _grad_keep_ranges(self):
         """[lo, hi) ranges the per-step zero-fill leaves alone: the encoder layers' gradients (overwritten by their backward) and the row-sparse table"""
         r = list(self._fresh_ranges)
@@ -214,14 +226,15 @@ class Trainer:
                 merged.append((lo, hi))
         return merged
 
-    def _sparse_table_range(self):
+    def _sparse_table_range(self, mark=True):
         """the word-embedding table's [lo, hi) in flat storage when it can be exchanged row-sparsely (parallel.GradReducer.sparse_rows):
         it must start its optimizer group's segment or the buffer, so that the dense ranges around it stay whole; else None"""
         emb = getattr(getattr(getattr(self.model, "text_bert", None), "embeddings", None), "word_embeddings", None)
         idx = getattr(getattr(emb, "weight", None), "_sam_index", None)
         if idx is None or idx + 1 >= len(self.flat.layout):
             return None
-        emb.weight._sam_sparse_reduce = True
+        if mark:
+            emb.weight._sam_sparse_reduce = True
         return self.flat.layout[idx][0], self.flat.layout[idx + 1][0]
 
     def current_lrs(self):

@@ -51,9 +51,20 @@ def _run(rank, world, port, out_dir):
     if world > 1:
         parallel.init_distributed()
     model, _ = _small_full_model(3, ("n", "s"), SHAPES)
-    tr = Trainer(model, base_lr=1e-3, seed=3)
+    dense = os.environ.get("SAM_TEST_DENSE_REDUCER") == "1" and world > 1
+    if dense:
+        # a caller-built reducer WITHOUT the row-sparse table exchange and without overlap (what bench.py --no-overlap builds): the word table
+        # is all-reduced densely, so the trainer must not walk it row-sparsely (rows touched only on the other rank would be skipped)
+        from sam_textvqa_amd.params import prepare
+        groups = model.get_optimizer_parameters(1e-3)
+        flat = prepare(model, groups=[g["params"] for g in groups])
+        tr = Trainer(model, base_lr=1e-3, seed=3, reducer=parallel.GradReducer(flat.grad, overlap=False))
+        assert tr.sparse is None and not tr.reducer.overlap and tr.reducer.sparse_hi == tr.reducer.sparse_lo
+    else:
+        tr = Trainer(model, base_lr=1e-3, seed=3)
     assert (tr.reducer is not None) == (world > 1)
-    if world > 1:
+    if world > 1 and not dense:
+        assert tr.sparse is not None
         assert tr.reducer.world_size == world and tr.reducer.overlap and tr.reducer.dense_lo > 0 and len(tr.reducer.regions) == 7
     losses = []
     per = 8 // world
@@ -101,6 +112,27 @@ def test_two_ranks_match_each_other_and_the_global_batch_run(tmp_path):
     cos = float(torch.dot(u_dp[moved], u_g[moved]) / (u_dp[moved].norm() * u_g[moved].norm()))
     rel = float((u_dp - u_g).norm() / u_g.norm())
     assert cos > 0.98 and rel < 0.2, (cos, rel)
+
+
+def test_two_ranks_with_a_dense_reducer_keep_identical_replicas(tmp_path, monkeypatch):
+    """a reducer that all-reduces the word-embedding table densely (no sparse_range, overlap off) with DIFFERENT question tokens
+    on the two ranks.  The row-sparse Adam walk must switch itself off there: the replicas end bit-identical and follow the single-process run."""
+    monkeypatch.setenv("SAM_TEST_DENSE_REDUCER", "1")
+    (r0, l0, p0, v0), (r1, l1, p1, v1) = _spawn(2, tmp_path)
+    monkeypatch.delenv("SAM_TEST_DENSE_REDUCER")
+    (_, lg, pg, vg), = _spawn(1, tmp_path)
+    assert torch.equal(p0, p1) and torch.equal(v0, v1), ((p0 - p1).abs().max().item(), (v0 - v1).abs().max().item())
+    for a, b, g in zip(l0, l1, lg):
+        assert abs((a + b) - g) <= 2e-3 * abs(g), (l0, l1, lg)
+    # the optimizer state of the table rows: every row either rank touched has moved on BOTH ranks (second moments non-zero), exactly as in the global run
+    from tests.test_model_gpu import _small_full_model
+    from sam_textvqa_amd.trainer import Trainer
+    model, _ = _small_full_model(3, ("n", "s"), SHAPES)
+    tr = Trainer(model, base_lr=1e-3, seed=3)
+    lo, hi, d, _ = tr.sparse
+    live_dp = (v0[lo:hi].view(-1, d) != 0).any(1)
+    live_g = (vg[lo:hi].view(-1, d) != 0).any(1)
+    assert torch.equal(live_dp, live_g) and int(live_g.sum()) > 8
 
 
 @pytest.mark.parametrize("payload", ["fp32", "bf16"])
