@@ -37,6 +37,8 @@
 #include "gemm_common.h"
 #include "sam_hip.h"
 
+extern "C" int sam_attn_words_per_row(int N);
+
 namespace {
 
 constexpr int NT = 256, NW = NT / 64, MAXL = 8, D = 768, F = 3072, HD = 64, KSPLIT = 4, NCH = D / 256, NXCD = 8;
@@ -114,7 +116,8 @@ __device__ __forceinline__ bool xcd_sync(const DArgs& a, const Grp& G, unsigned 
     while (l2_read(bar) < epoch) {
       __builtin_amdgcn_s_sleep(1);
       if ((++spins & 1023u) == 0 && (spins > SPIN_LIMIT || __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int expected = 0;        // keep an earlier, more specific code (2 = uneven XCD deal): only an unset word becomes "barrier timed out"
+        __hip_atomic_compare_exchange_strong(a.err, &expected, 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         good = 0;
         break;
       }
@@ -574,7 +577,8 @@ extern "C" int sam_greedy_decode_steps(const sam_decode_desc* d, void* ws, int64
     L.bqkv = s.bqkv; L.bo = s.bo; L.b1 = s.b1; L.b2 = s.b2; L.g1 = s.ln1_g; L.be1 = s.ln1_b; L.g2 = s.ln2_g; L.be2 = s.ln2_b;
     L.qkv = (bf16_t*)s.qkv; L.allow = s.allow; L.allow_sb = s.allow_stride_b; L.allow_sh = s.allow_stride_h;
   }
-  a.n_layers = d->n_layers; a.B = d->B; a.spx = (d->B + NXCD - 1) / NXCD; a.N = d->N; a.n_enc = d->n_enc; a.S = d->S; a.H = d->H; a.NWORDS = (d->N + 31) / 32;
+  a.n_layers = d->n_layers; a.B = d->B; a.spx = (d->B + NXCD - 1) / NXCD; a.N = d->N; a.n_enc = d->n_enc; a.S = d->S; a.H = d->H;
+  a.NWORDS = sam_attn_words_per_row(d->N);      // the ROW STRIDE of the allow masks as the packers write them (1, 2, 4, 6, 8 or 12 words), not ceil(N / 32)
   a.V = d->V; a.No = d->No; a.t_begin = d->t_begin; a.t_end = d->t_end;
   a.ldf = d->ld_fixed; a.ld_pos = d->ld_pos; a.ld_type = d->ld_type;
   a.scale_log2 = d->scale * 1.44269504088896341f; a.eps = d->ln_eps; a.eps_emb = d->emb_ln_eps; a.ptr_scale = d->ptr_scale;

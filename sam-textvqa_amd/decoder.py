@@ -117,6 +117,27 @@ def fused_enabled():
     return os.environ.get("SAM_DECODE_FUSED", "1") != "0"
 
 
+_CU_COUNT = None
+
+
+def _cu_count():
+    global _CU_COUNT
+    if _CU_COUNT is None:
+        _CU_COUNT = int(torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count)
+    return _CU_COUNT
+
+
+_warned_fallback = False
+
+
+def _log_fallback(why):
+    global _warned_fallback
+    if not _warned_fallback:
+        _warned_fallback = True
+        import logging
+        logging.getLogger(__name__).warning("persistent decoding kernel unavailable (%s): decoding with the per-kernel step from here on", why)
+
+
 class DecodeSession:
     """static buffers + the two captured graphs for one (model, input shapes, beam size)"""
 
@@ -221,6 +242,8 @@ class DecodeSession:
         m, mmt = self.model, self.model.mmt
         r, s = self.rows, self.steps
         if self.beam or s < 2 or not fused_enabled():
+            return False
+        if r > 128 or _cu_count() % 8 != 0:          # the kernel's own limits: 16 rows per XCD x 8 XCDs, a CU count dealt evenly over the eight XCDs
             return False
         layers = []
         eps = None
@@ -353,12 +376,31 @@ class DecodeSession:
                 self.graph_step.replay()
                 last = self.out_step
         if self.fused:
+            inject = os.environ.get("SAM_DECODE_INJECT_ERR")          # (test hook: pretend the kernel reported this code)
+            if inject:
+                self._fused_ws[256] = int(inject)
             code = int(self._fused_ws[256].item())
             if code != 0:
+                # the persistent launch could not own the device (a barrier timed out: other work held CUs) or the device does not deal workgroups to
+                # its eight XCDs evenly: whatever it wrote is discarded and the batch is decoded again by the per-kernel step, which this session
+                # keeps from here on (the reference's loop, sa_m4c.py:285-302, cannot fail this way)
                 self._fused_ws.zero_()
-                raise capi.SamHipError("sam_greedy_decode_steps failed on the device: " + ("the device does not deal the launch to eight XCDs evenly" if code == 2 else
-                                       "a barrier timed out (the launch did not have the device to itself?)"))
+                _log_fallback("the device does not deal the launch to eight XCDs evenly" if code == 2 else "a barrier timed out: the launch did not have the device to itself")
+                last = self._fall_back(batch_dict)
         return self._results(batch_dict, last)
+
+    def _fall_back(self, batch_dict):
+        """drop the persistent kernel for this session and decode the current batch with the per-kernel step (eagerly; the graphs are re-captured,
+        without the persistent kernel, on the next run)"""
+        self.fused = False
+        self.graph_first = self.graph_step = None
+        self.load_inputs(batch_dict)
+        self._first()
+        last = self.out_first
+        for _ in range(self.steps - 1):
+            self._step()
+            last = self.out_step
+        return last
 
     def _capture(self):
         # Dead sessions (a model and its sessions form a reference cycle: only the cyclic collector frees them) own hipGraphs and their private
@@ -383,7 +425,16 @@ class DecodeSession:
         with torch.cuda.stream(st):
             self._first()
             if self.steps > 1:
-                self._steps_fused() if self.fused else self._step()
+                if self.fused:
+                    try:
+                        self._steps_fused()
+                    except capi.SamHipError as e:        # a shape / device the kernel declines after all: the per-kernel step takes over
+                        _log_fallback(str(e))
+                        self.fused = False
+                        self._first()
+                        self._step()
+                else:
+                    self._step()
         cur.wait_stream(st)
         torch.cuda.synchronize()
         g1 = torch.cuda.CUDAGraph()
@@ -401,7 +452,11 @@ class DecodeSession:
         r, s = self.rows, self.steps
         scores = torch.cat([fixed.view(r, s, -1), dyn], dim=-1)
         batch_dict["scores"] = scores
-        batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"] = fixed.view(r, s, -1), dyn
+        # the two blocks as views of the fresh concatenation, not of the session's static buffers (which the next batch overwrites in place: an evaluator
+        # that collects per-batch outputs must not see them change).  text_bert_emb / obj_mmt_in / ocr_mmt_in below ARE the session's buffers: valid
+        # until the next forward, as intermediate activations are
+        n_fixed = fixed.view(r, s, -1).shape[-1]
+        batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"] = scores[..., :n_fixed], scores[..., n_fixed:]
         batch_dict["train_prev_inds"] = self.prev.clone()
         batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"] = self.enc
         seq = self.seq.clone()
