@@ -573,7 +573,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192 || ft == 2256, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192, 1256, 1448, 2256 or 3192");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192, 1256, 1448 or 3192");
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T

@@ -537,7 +537,6 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
 }  // namespace
 
 int samgemm::gemm8_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, int tile, hipStream_t st) {
-  if (tile == 2256) return gemm4_launch(a_in, lay, e, c_is_f32, st);
   GemmArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("SAM_GEMM8_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg; }
   // the DMA addresses are 32-bit byte offsets from the operand base; k-tiles are whole; nothing here splits K or reduces a bias gradient

@@ -310,8 +310,7 @@ inline int device_cu_count() {
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.
 int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
-// two 4-wave blocks per CU, 256 x 128 x 32 tiles (gemm4.hip): force_tile 2256, or chosen by gemm8_launch where it measured faster
-int gemm4_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, hipStream_t st);
+// (the round-3 experiment with two 4-wave blocks per CU, 256 x 128 x 32 tiles, measured 0.78x the 8-wave k-loop: it lives in tools/probes/gemm4.hip, outside the library)
 // grouped weight gradients on the 8-wave core (gemm8w.hip): 256x256 tiles, the K range of each tile split over a PAIR of blocks that exchange
 // halves inside the launch.  descs[0].ws / ws_bytes: the exchange workspace (gemm8w_ws_bytes(total tiles); its first words are the pair flags,
 // which must be zero before the first launch and are left zero by every launch).  SAM_ERR_UNSUPPORTED: not a problem set for this kernel.

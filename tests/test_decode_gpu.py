@@ -477,3 +477,38 @@ def test_persistent_decoding_kernel_failure_falls_back_to_the_per_kernel_step(mo
             assert int(ses._fused_ws[256].item()) == 0
         for a, b in zip(want, got):
             assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+
+
+def test_greedy_decoding_at_the_stress_shape(monkeypatch):
+    """BASELINE configs[4] shapes (350 tokens: 200 obj + 100 OCR + 30 decoding steps): the persistent kernel declines (it is built for <= 256 tokens and
+    <= 64 OCR slots: DecodeSession._fused_plan returns False, nothing raises) and the captured per-kernel step decodes -- compared with the
+    reference-style 30 full forwards of the same model and with the fp32 oracle's greedy loop"""
+    from sam_textvqa_amd.params import prepare
+    from sam_textvqa_amd.synthetic import clone_batch
+    from tests.test_model_gpu import _small_full_model
+    shapes = (20, 200, 100, 30)
+    model, ref = _small_full_model(3, ("n", "s", "s"), shapes, vocab=300)
+    model.cuda().eval()
+    prepare(model)
+    outs = {}
+    for mode in ("full", "session"):
+        model.decode_cache = mode != "full"
+        monkeypatch.setenv("SAM_DECODE_SESSION", "1" if mode == "session" else "0")
+        monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
+        monkeypatch.setenv("SAM_DECODE_FUSED", "1")
+        model.__dict__.pop("_sam_decode_sessions", None)
+        bd = _batch(3, shapes, 300, 61, "cuda")
+        with torch.no_grad():
+            sc = model(bd)["textvqa_scores"]
+        outs[mode] = (sc.float().cpu(), bd["train_prev_inds"].cpu())
+        if mode == "session":
+            ses = next(iter(model._sam_decode_sessions.values()))
+            assert ses.fused is False and ses.steps == 30 and ses.n == 350
+    a, b = outs["full"], outs["session"]
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    with torch.no_grad():
+        want = ref.eval()(clone_batch(_batch(3, shapes, 300, 61, "cpu")))["textvqa_scores"].float()
+    live = want > -9000
+    err = ((b[0] - want).abs()[live].max() / want[live].abs().max()).item()
+    print("PARITY greedy decode at the stress shape (350 tokens, 30 steps) vs fp32 oracle: scores rel err %.2e, tokens equal %s" % (err, torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:])))
+    assert err < 1e-2 and torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:])

@@ -1,3 +1,5 @@
+// NOT part of libsam_hip.so since round 4: the two-4-wave-blocks-per-CU GEMM of round 3 (force_tile 2256), built, parity-tested and measured slower
+// (k-loop 0.78x the 8-wave kernel: profiles/r3z_micro_gemm.txt).  Kept as a probe; it needs csrc/gemm_common.h + gemm8_dev.h to compile.
 // bf16 MFMA GEMM, TWO 4-wave blocks per CU (gfx950): the forward / dgrad nn.Linear sites whose fused epilogue is a large part of the launch.
 //
 // The 8-wave kernels (gemm8.hip) give a CU to ONE block: while that block converts, activates and stores a finished tile (4-12 us per tile: VALU
