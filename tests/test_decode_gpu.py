@@ -505,7 +505,8 @@ def test_greedy_decoding_at_the_stress_shape(monkeypatch):
             ses = next(iter(model._sam_decode_sessions.values()))
             assert ses.fused is False and ses.steps == 30 and ses.n == 350
     a, b = outs["full"], outs["session"]
-    assert torch.equal(a[1], b[1]) and torch.equal(a[0], b[0])
+    live = a[0] > -9000          # (not bit-identical: 90 decoder rows go through other GEMM tiles / split-K than the 1050 rows of a full pass)
+    assert torch.equal(a[1], b[1]) and ((a[0] - b[0]).abs()[live].max() / a[0][live].abs().max()).item() < 6e-3
     with torch.no_grad():
         want = ref.eval()(clone_batch(_batch(3, shapes, 300, 61, "cpu")))["textvqa_scores"].float()
     live = want > -9000
