@@ -422,16 +422,25 @@ def main():
     rot = [batch] + [make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=5000 + 97 * j + rank) for j in range(1, max(1, args.rotate))]
 
     def small_items(bd):
-        return {k: v.clone() for k, v in bd.items() if torch.is_tensor(v) and v.numel() * v.element_size() < (1 << 20)}
+        return {k: v.clone().contiguous() for k, v in bd.items() if torch.is_tensor(v) and v.numel() * v.element_size() < (1 << 20) and v.element_size() in (4, 8)}
     rot_small = [small_items(b) for b in rot]
     rot = rot[:1] if len(rot) == 1 else [None] * len(rot)        # (only the small tensors of the other batches are kept)
+
+    from sam_textvqa_amd import ops as _ops
+
+    def _as_f32_rows(t):          # any 4- / 8-byte-element tensor as a [1, 1, n] fp32 view: a raw copy for sam_copy_blocks
+        return t.view(-1).view(torch.float32).view(1, 1, -1)
 
     def next_batch(step_idx, base):
         bd = clone_batch(base)
         if len(rot) > 1:
             src = rot_small[step_idx % len(rot)]
-            # in place: `base` is the captured step's own input buffers in graph mode (no staging copy afterwards); one multi-tensor copy per dtype
-            torch._foreach_copy_([bd[k] for k in src], list(src.values()))
+            # in place: `base` is the captured step's own input buffers in graph mode (no staging copy afterwards).  ONE launch for the eight small
+            # tensors (sam_copy_blocks; torch._foreach_copy_ issued a copy kernel per tensor)
+            try:
+                _ops.copy_blocks([(_as_f32_rows(v), _as_f32_rows(bd[k])) for k, v in src.items()])
+            except Exception:
+                torch._foreach_copy_([bd[k] for k in src], list(src.values()))
         return bd
 
     for j in range(args.warmup):

@@ -313,6 +313,281 @@ __global__ __launch_bounds__(64 * NKT) void attn_bwd_fused_kernel(AttnArgs a) {
   }
 }
 
+// ---- sequences of 193 .. 384 tokens (the stress shape's 350): the same one-pass scheme on 192 x 192 SUB-PROBLEMS -------------------------
+// Q | dO and K | V of a head no longer fit the CU's LDS next to the dS exchange, so a block walks (key chunk kh) x (query chunk qh), chunks of
+// 192 rows: every sub-problem stages its Q, dO (and for qh = 0 its K, V) chunk, runs phase 1 (S, P, dP, dS once per score; dK / dV of the key
+// chunk accumulate over qh in registers) and phase 2 (dQ of the query chunk accumulates over kh in registers: 2 x 16 more).  The fp16 block scales are
+// per CHUNK; an accumulator that lives across chunks is moved to the new chunk's power-of-two scale before the first MFMA adds to it (exact).
+// delta of a query row is computed once (kh = 0) and kept in LDS.  No cross-head prefetch here (one round of 1.5 heads per CU at the stress batch).
+template <bool DROP>
+__global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
+  constexpr int NKT = 12;
+  typedef FusedLds<NKT> L;
+  constexpr int NPAD = L::NPAD, NW = L::NW, NT = 64 * NKT, CH = NPAD;
+  constexpr int NBW = (NPAD * NW + NT - 1) / NT;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* Qs = smem + L::OFF_Q;
+  unsigned char* dOs = smem + L::OFF_DO;
+  unsigned char* Ks = smem + L::OFF_K;
+  unsigned char* dSs = smem + L::OFF_DS;
+  float* nl_s = reinterpret_cast<float*>(smem + L::OFF_NL);
+  float* nd_s = reinterpret_cast<float*>(smem + L::OFF_ND);
+  uint32_t* naT = reinterpret_cast<uint32_t*>(smem + L::OFF_NA);
+  uint32_t* kpT = reinterpret_cast<uint32_t*>(smem + L::OFF_KP);
+  unsigned* red = reinterpret_cast<unsigned*>(smem + L::OFF_RED);
+  float* dl_s = reinterpret_cast<float*>(smem + L::BYTES);          // raw delta of both query chunks, f32 [2][NPAD]
+
+  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int N = a.N, Dm = a.H * HD, NWR = a.NW;                       // NWR: words per allow / keep row in memory (12)
+  const int64_t ld = 3 * (int64_t)Dm;
+  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  const bf16_t* obase = a.out + (int64_t)b * N * Dm + h * HD;
+  const bf16_t* olbase = a.out_lo + (int64_t)b * N * Dm + h * HD;
+  const bf16_t* dobase = a.dout + (int64_t)b * N * Dm + h * HD;
+  const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh;
+  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int n_chunks = (N + CH - 1) / CH;                               // 2
+
+  f32x4 dq[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) dq[c][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int e_dq[2] = {0, 0};                                                // exponent the dQ accumulators currently carry (es + ek of the last sub-problem)
+
+  for (int kh = 0; kh < n_chunks; ++kh) {
+    const int k0 = kh * CH, key = k0 + wave * 16 + i, kc = key < N ? key : N - 1;
+    f32x4 dk[4], dv[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    int e_dk = 0, e_dv = 0, ck = 0, cv = 0, eq_last = 0;
+    f16x8 vf[2], kf[2];
+    for (int qh = 0; qh < n_chunks; ++qh) {
+      const int q0 = qh * CH;
+      // ---- staging of the sub-problem
+      uint4 rq[2], rk[2], rd[2], rv[2];
+      unsigned mq = 0, mk = 0, md = 0, mv = 0;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int c = tid + j * NT, row = c >> 3, ch = c & 7;
+        const int qr = q0 + row, qrc = qr < N ? qr : N - 1, kr = k0 + row, krc = kr < N ? kr : N - 1;
+        rq[j] = *reinterpret_cast<const uint4*>(qbase + (int64_t)qrc * ld + ch * 8);
+        rd[j] = *reinterpret_cast<const uint4*>(dobase + (int64_t)qrc * Dm + ch * 8);
+        if (qr >= N) { rq[j] = make_uint4(0, 0, 0, 0); rd[j] = rq[j]; }
+        mq = absmax_acc4(mq, rq[j]); md = absmax_acc4(md, rd[j]);
+        if (qh == 0) {
+          rk[j] = *reinterpret_cast<const uint4*>(qbase + Dm + (int64_t)krc * ld + ch * 8);
+          if (kr >= N) rk[j] = make_uint4(0, 0, 0, 0);
+          mk = absmax_acc4(mk, rk[j]);
+        }
+        if (kh == 0) {      // delta of this query chunk: dO . (O + O_lo), once
+          typedef __attribute__((ext_vector_type(2))) __bf16 hb2;
+          const uint4 oh = *reinterpret_cast<const uint4*>(obase + (int64_t)qrc * Dm + ch * 8);
+          const uint4 ol = *reinterpret_cast<const uint4*>(olbase + (int64_t)qrc * Dm + ch * 8);
+          float acc = 0.f;
+          const unsigned dv4[4] = {rd[j].x, rd[j].y, rd[j].z, rd[j].w}, hv[4] = {oh.x, oh.y, oh.z, oh.w}, lv[4] = {ol.x, ol.y, ol.z, ol.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hb2, dv4[e]), __builtin_bit_cast(hb2, hv[e]), acc, false);
+            acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(hb2, dv4[e]), __builtin_bit_cast(hb2, lv[e]), acc, false);
+          }
+          acc += __shfl_xor(acc, 1); acc += __shfl_xor(acc, 2); acc += __shfl_xor(acc, 4);
+          if (ch == 0) dl_s[qh * NPAD + row] = acc;
+        }
+      }
+      if (qh == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          rv[ks] = *reinterpret_cast<const uint4*>(qbase + 2 * Dm + (int64_t)kc * ld + 32 * ks + 8 * g);
+          if (key >= N) rv[ks] = make_uint4(0, 0, 0, 0);
+          mv = absmax_acc4(mv, rv[ks]);
+        }
+      }
+      unsigned m01 = absmax_fold(mq) | (absmax_fold(mk) << 16), m23 = absmax_fold(md) | (absmax_fold(mv) << 16);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        m01 = pk_max_u16(m01, (unsigned)__shfl_xor((int)m01, o));
+        m23 = pk_max_u16(m23, (unsigned)__shfl_xor((int)m23, o));
+      }
+      if (lane == 0) *reinterpret_cast<uint2*>(red + 2 * wave) = make_uint2(m01, m23);
+      for (int c = tid; c < NPAD * NW; c += NT) {
+        const int qi = c / NW, w = c - qi * NW, qr = q0 + qi;
+        naT[w * NPAD + qi] = qr < N ? ~ap[(int64_t)qr * NWR + kh * NW + w] : 0xffffffffu;
+        if (DROP) kpT[w * NPAD + qi] = qr < N ? a.keep[((int64_t)bh * N + qr) * NWR + kh * NW + w] : 0u;
+      }
+      for (int qi = tid; qi < NPAD; qi += NT) nl_s[qi] = q0 + qi < N ? (float)P_SHIFT - a.lse2[(int64_t)bh * N + q0 + qi] : -INFINITY;
+      __syncthreads();
+      unsigned mm01 = 0, mm23 = 0;
+#pragma unroll
+      for (int w = 0; w < NKT; ++w) {
+        const uint2 r2 = *reinterpret_cast<const uint2*>(red + 2 * w);
+        mm01 = pk_max_u16(mm01, r2.x); mm23 = pk_max_u16(mm23, r2.y);
+      }
+      const int cq = scale_c_of(mm01 & 0xffffu), cd = scale_c_of(mm23 & 0xffffu);
+      if (qh == 0) { ck = scale_c_of(mm01 >> 16); cv = scale_c_of(mm23 >> 16); }
+      const int eq = 112 - cq, ek = 112 - ck, ed = 112 - cd, ev = 112 - cv, es = ed + ev - 22 - a.ds_sh;
+      {
+        const unsigned sq = csub_of(cq), sk = csub_of(ck), sd = csub_of(cd);
+        const int e_nd = ed + ev - 36 - a.ds_sh;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int c = tid + j * NT, row = c >> 3, ch = c & 7, off = tile_off(row, ch);
+          *reinterpret_cast<uint4*>(Qs + off) = bf2h_pk4(rq[j], sq);
+          *reinterpret_cast<uint4*>(dOs + off) = bf2h_pk4(rd[j], sd);
+          if (qh == 0) *reinterpret_cast<uint4*>(Ks + off) = bf2h_pk4(rk[j], sk);
+        }
+        for (int qi = tid; qi < NPAD; qi += NT) nd_s[qi] = ldexpf(-a.scale * dl_s[qh * NPAD + qi], e_nd);     // (dl_s of this chunk: written before the barrier above)
+      }
+      if (qh == 0) {
+        const unsigned sv = csub_of(cv);
+        vf[0] = __builtin_bit_cast(f16x8, bf2h_pk4(rv[0], sv));
+        vf[1] = __builtin_bit_cast(f16x8, bf2h_pk4(rv[1], sv));
+      }
+      __syncthreads();
+      if (qh == 0) { kf[0] = as_f16(lds_row_frag(Ks, 16 * wave + i, g)); kf[1] = as_f16(lds_row_frag(Ks, 16 * wave + i, 4 + g)); }
+      // accumulators that live across chunks: onto this sub-problem's scales
+      {
+        const int n_dk = es + eq, n_dv = P_SHIFT + ed;
+        if (qh > 0 && (n_dk != e_dk || n_dv != e_dv)) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { dk[dt][r] = ldexpf(dk[dt][r], n_dk - e_dk); dv[dt][r] = ldexpf(dv[dt][r], n_dv - e_dv); }
+        }
+        e_dk = n_dk; e_dv = n_dv; eq_last = eq;
+      }
+      // ---- phase 1
+      const int wsel = wave >> 1;
+      const unsigned bit = (unsigned)((wave & 1) * 16 + i);
+      const float cs = ldexpf(a.scale_log2, -eq - ek);
+#pragma unroll
+      for (int s = 0; s < NKT / 2; ++s) {
+        typedef __attribute__((ext_vector_type(4))) unsigned u4;
+        u4 ppk, dpk;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int t = 2 * s + half, q4 = 16 * t + 4 * g;
+          const uint4 na4 = *reinterpret_cast<const uint4*>(naT + wsel * NPAD + q4);
+          const f32x4 nl4 = *reinterpret_cast<const f32x4*>(nl_s + q4);
+          const f32x4 nd4 = *reinterpret_cast<const f32x4*>(nd_s + q4);
+          const unsigned nav[4] = {na4.x, na4.y, na4.z, na4.w};
+          f32x4 acc_s, acc_dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_s[r] = __int_as_float(__builtin_amdgcn_sbfe((int)nav[r], bit, 1u) & (int)0xff800000u);
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) {
+            acc_s = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(lds_row_frag(Qs, 16 * t + i, 4 * ks + g)), kf[ks], acc_s, 0, 0, 0);
+            acc_dp = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(lds_row_frag(dOs, 16 * t + i, 4 * ks + g)), vf[ks], acc_dp, 0, 0, 0);
+          }
+          float p[4], ds[4];
+          if (DROP) {
+            const uint4 kp4 = *reinterpret_cast<const uint4*>(kpT + wsel * NPAD + q4);
+            const unsigned kpv[4] = {kp4.x, kp4.y, kp4.z, kp4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int km = __builtin_amdgcn_sbfe((int)kpv[r], bit, 1u);
+              const float pr = __builtin_amdgcn_exp2f(fmaf(acc_s[r], cs, nl4[r]));
+              const float dpe = __int_as_float(__float_as_int(acc_dp[r]) & km);
+              ds[r] = pr * fmaf(dpe, a.ds_c1, nd4[r]);
+              p[r] = __int_as_float(__float_as_int(pr) & km);
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              p[r] = __builtin_amdgcn_exp2f(fmaf(acc_s[r], cs, nl4[r]));
+              ds[r] = p[r] * fmaf(acc_dp[r], a.ds_c1, nd4[r]);
+            }
+          }
+          ppk[2 * half] = pack_f16x2(p[0], p[1]); ppk[2 * half + 1] = pack_f16x2(p[2], p[3]);
+          dpk[2 * half] = pack_f16x2(ds[0], ds[1]); dpk[2 * half + 1] = pack_f16x2(ds[2], ds[3]);
+          *reinterpret_cast<uint2*>(dSs + ds_off<NKT>(16 * wave + i, t, g)) = make_uint2(dpk[2 * half], dpk[2 * half + 1]);
+        }
+        const f16x8 pa = __builtin_bit_cast(f16x8, ppk), dsa = __builtin_bit_cast(f16x8, dpk);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+          dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(lds_col_frag(dOs, s, dt, i, g)), pa, dv[dt], 0, 0, 0);
+          dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(lds_col_frag(Qs, s, dt, i, g)), dsa, dk[dt], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      // ---- phase 2: dQ of query tile (qh, wave) += dS . K over this key chunk
+      {
+        const int n_dq = es + ek;
+        if (kh > 0 && n_dq != e_dq[qh]) {
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dq[qh][dt][r] = ldexpf(dq[qh][dt][r], n_dq - e_dq[qh]);
+        }
+        e_dq[qh] = n_dq;
+#pragma unroll
+        for (int s = 0; s < NKT / 2; ++s) {
+          const int kr = 32 * s + 4 * g + (i >> 2);
+          const f16x8 dsf = as_f16(cat4(lds_read_tr16(dSs + ds_off<NKT>(kr, wave, i & 3)), lds_read_tr16(dSs + ds_off<NKT>(kr + 16, wave, i & 3))));
+#pragma unroll
+          for (int dt = 0; dt < 4; ++dt) dq[qh][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(lds_col_frag(Ks, s, dt, i, g)), dsf, dq[qh][dt], 0, 0, 0);
+        }
+      }
+      __syncthreads();                 // Q, dO, dS and the scalars are rewritten by the next sub-problem
+    }
+    // ---- dK, dV of this key chunk
+    {
+      const float fv = ldexpf(a.inv_keep, 0);
+      bf16_t* dst = a.dqkv + ((int64_t)b * N + kc) * ld + h * HD + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float vk[8], vv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sk2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dk[2 * jp][r]), __float_as_uint(dk[2 * jp + 1][r]), false, false);
+          const auto sv2 = __builtin_amdgcn_permlane16_swap(__float_as_uint(dv[2 * jp][r]), __float_as_uint(dv[2 * jp + 1][r]), false, false);
+          vk[r] = ldexpf(__uint_as_float(sk2[0]), -e_dk); vk[4 + r] = ldexpf(__uint_as_float(sk2[1]), -e_dk);
+          vv[r] = ldexpf(__uint_as_float(sv2[0]) * fv, -e_dv); vv[4 + r] = ldexpf(__uint_as_float(sv2[1]) * fv, -e_dv);
+        }
+        if (key < N) {
+          *reinterpret_cast<uint4*>(dst + Dm + 32 * jp) = make_uint4(pack_bf16x2(vk[0], vk[1]), pack_bf16x2(vk[2], vk[3]), pack_bf16x2(vk[4], vk[5]), pack_bf16x2(vk[6], vk[7]));
+          *reinterpret_cast<uint4*>(dst + 2 * Dm + 32 * jp) = make_uint4(pack_bf16x2(vv[0], vv[1]), pack_bf16x2(vv[2], vv[3]), pack_bf16x2(vv[4], vv[5]), pack_bf16x2(vv[6], vv[7]));
+        }
+      }
+    }
+    (void)eq_last;
+  }
+  // ---- dQ of both query chunks
+#pragma unroll
+  for (int qh = 0; qh < 2; ++qh) {
+    if (qh < n_chunks) {
+      const int q = qh * CH + wave * 16 + i, qcl = q < N ? q : N - 1;
+      bf16_t* dst = a.dqkv + ((int64_t)b * N + qcl) * ld + h * HD + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+      for (int jp = 0; jp < 2; ++jp) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(dq[qh][2 * jp][r]), __float_as_uint(dq[qh][2 * jp + 1][r]), false, false);
+          v[r] = ldexpf(__uint_as_float(sw[0]), -e_dq[qh]); v[4 + r] = ldexpf(__uint_as_float(sw[1]), -e_dq[qh]);
+        }
+        if (q < N) *reinterpret_cast<uint4*>(dst + 32 * jp) = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+      }
+    }
+  }
+}
+
+int launch_fused_long(const AttnArgs& a, hipStream_t st) {
+  constexpr int BYTES = FusedLds<12>::BYTES + 2 * FusedLds<12>::NPAD * 4;
+  static_assert(BYTES <= 160 * 1024, "the long-sequence one-pass backward must fit one CU's LDS");
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_long_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_long_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES);
+    once = true;
+  }
+  if (a.keep) attn_bwd_fused_long_kernel<true><<<dim3(a.B * a.H), dim3(768), BYTES, st>>>(a);
+  else attn_bwd_fused_long_kernel<false><<<dim3(a.B * a.H), dim3(768), BYTES, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 template <int NKT>
 int launch_fused(const AttnArgs& a, hipStream_t st) {
   typedef FusedLds<NKT> L;
@@ -348,8 +623,9 @@ int launch_fused(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// largest sequence the one-pass backward takes (12 key tiles: Q, K, dO tiles + the dS exchange fill the CU's 160 KB of LDS)
-extern "C" int sam_attn_bwd_fused_max_n(void) { return 192; }
+// largest sequence the one-pass backward takes: up to 192 tokens a head is one problem (12 key tiles: Q, K, dO tiles + the dS exchange fill the CU's
+// 160 KB of LDS), 193 .. 384 tokens run as 2 x 2 sub-problems of 192 inside one block (attn_bwd_fused_long_kernel)
+extern "C" int sam_attn_bwd_fused_max_n(void) { return 384; }
 
 extern "C" int sam_attn_bwd_fused(const void* dout, const void* qkv, const void* out, const void* out_lo, const float* lse2, const uint32_t* allow,
                                   int64_t allow_stride_b, int64_t allow_stride_h, const uint32_t* keep, int B, int N, int H, int head_dim,
@@ -359,10 +635,6 @@ extern "C" int sam_attn_bwd_fused(const void* dout, const void* qkv, const void*
   if (rc) return rc;
   SAM_REQUIRE(dout && qkv && out && out_lo && lse2 && allow && dqkv, "sam_attn_bwd_fused: null pointer");
   SAM_REQUIRE(a.thr16 == 0 || keep, "sam_attn_bwd_fused: dropout needs the keep bits written by sam_attn_fwd_train");
-  if (a.nkt > 12) {
-    sam_set_error("sam_attn_bwd_fused: N=%d exceeds the one-pass limit of %d keys (use sam_attn_bwd)", N, sam_attn_bwd_fused_max_n());
-    return SAM_ERR_UNSUPPORTED;
-  }
   a.qkv = (const bf16_t*)qkv; a.dout = (const bf16_t*)dout; a.out = (const bf16_t*)out; a.out_lo = (const bf16_t*)out_lo; a.dqkv = (bf16_t*)dqkv;
   a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h; a.keep = a.thr16 ? keep : nullptr;
   a.lse2 = lse2;
@@ -375,6 +647,10 @@ extern "C" int sam_attn_bwd_fused(const void* dout, const void* qkv, const void*
   a.ds_sh = sh;
   a.ds_c1 = ldexpf(kappa, -36 - sh);
   hipStream_t st = (hipStream_t)stream;
+  if (a.nkt > 12) {
+    if (a.nkt != 24) return SAM_ERR_UNSUPPORTED;         // 16 key tiles (193 .. 256 tokens) have 8-word mask rows: the two-kernel form keeps those
+    return launch_fused_long(a, st);
+  }
   switch (a.nkt) {
     case 2: return launch_fused<2>(a, st);
     case 4: return launch_fused<4>(a, st);
