@@ -337,7 +337,7 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
   unsigned* red = reinterpret_cast<unsigned*>(smem + L::OFF_RED);
   float* dl_s = reinterpret_cast<float*>(smem + L::BYTES);          // raw delta of both query chunks, f32 [2][NPAD]
 
-  const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
+  const int bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int N = a.N, Dm = a.H * HD, NWR = a.NW;                       // NWR: words per allow / keep row in memory (12)
   const int64_t ld = 3 * (int64_t)Dm;
   const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
@@ -345,8 +345,15 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
   const bf16_t* olbase = a.out_lo + (int64_t)b * N * Dm + h * HD;
   const bf16_t* dobase = a.dout + (int64_t)b * N * Dm + h * HD;
   const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh;
-  const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int n_chunks = (N + CH - 1) / CH;                               // 2
+  int lane, tid, i, g;
+  auto derive_lane = [&]() {      // re-derived (opaquely) per sub-problem: otherwise every LDS address becomes a loop invariant held in a register across both loops
+    int l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    lane = l; tid = wave * 64 + l; i = l & 15; g = l >> 4;
+  };
+  derive_lane();
 
   f32x4 dq[2][4];
 #pragma unroll
@@ -356,13 +363,14 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
   int e_dq[2] = {0, 0};                                                // exponent the dQ accumulators currently carry (es + ek of the last sub-problem)
 
   for (int kh = 0; kh < n_chunks; ++kh) {
-    const int k0 = kh * CH, key = k0 + wave * 16 + i, kc = key < N ? key : N - 1;
+    const int k0 = kh * CH;
     f32x4 dk[4], dv[4];
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     int e_dk = 0, e_dv = 0, ck = 0, cv = 0, eq_last = 0;
     f16x8 vf[2], kf[2];
     for (int qh = 0; qh < n_chunks; ++qh) {
+      derive_lane();
       const int q0 = qh * CH;
       // ---- staging of the sub-problem
       uint4 rq[2], rk[2], rd[2], rv[2];
@@ -396,6 +404,7 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
         }
       }
       if (qh == 0) {
+        const int key = k0 + wave * 16 + i, kc = key < N ? key : N - 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
           rv[ks] = *reinterpret_cast<const uint4*>(qbase + 2 * Dm + (int64_t)kc * ld + 32 * ks + 8 * g);
@@ -412,8 +421,9 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
       if (lane == 0) *reinterpret_cast<uint2*>(red + 2 * wave) = make_uint2(m01, m23);
       for (int c = tid; c < NPAD * NW; c += NT) {
         const int qi = c / NW, w = c - qi * NW, qr = q0 + qi;
-        naT[w * NPAD + qi] = qr < N ? ~ap[(int64_t)qr * NWR + kh * NW + w] : 0xffffffffu;
-        if (DROP) kpT[w * NPAD + qi] = qr < N ? a.keep[((int64_t)bh * N + qr) * NWR + kh * NW + w] : 0u;
+        const bool in_row = qr < N && kh * NW + w < NWR;          // (16 key tiles: 8-word rows, the second chunk has two of them)
+        naT[w * NPAD + qi] = in_row ? ~ap[(int64_t)qr * NWR + kh * NW + w] : 0xffffffffu;
+        if (DROP) kpT[w * NPAD + qi] = in_row ? a.keep[((int64_t)bh * N + qr) * NWR + kh * NW + w] : 0u;
       }
       for (int qi = tid; qi < NPAD; qi += NT) nl_s[qi] = q0 + qi < N ? (float)P_SHIFT - a.lse2[(int64_t)bh * N + q0 + qi] : -INFINITY;
       __syncthreads();
@@ -533,7 +543,9 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
     }
     // ---- dK, dV of this key chunk
     {
-      const float fv = ldexpf(a.inv_keep, 0);
+      derive_lane();
+      const int key = k0 + wave * 16 + i, kc = key < N ? key : N - 1;
+      const float fv = a.inv_keep;
       bf16_t* dst = a.dqkv + ((int64_t)b * N + kc) * ld + h * HD + 16 * (g & 1) + 8 * (g >> 1);
 #pragma unroll
       for (int jp = 0; jp < 2; ++jp) {
@@ -554,6 +566,7 @@ __global__ __launch_bounds__(768) void attn_bwd_fused_long_kernel(AttnArgs a) {
     (void)eq_last;
   }
   // ---- dQ of both query chunks
+  derive_lane();
 #pragma unroll
   for (int qh = 0; qh < 2; ++qh) {
     if (qh < n_chunks) {
@@ -648,8 +661,7 @@ extern "C" int sam_attn_bwd_fused(const void* dout, const void* qkv, const void*
   a.ds_c1 = ldexpf(kappa, -36 - sh);
   hipStream_t st = (hipStream_t)stream;
   if (a.nkt > 12) {
-    if (a.nkt != 24) return SAM_ERR_UNSUPPORTED;         // 16 key tiles (193 .. 256 tokens) have 8-word mask rows: the two-kernel form keeps those
-    return launch_fused_long(a, st);
+    return launch_fused_long(a, st);                     // 16 or 24 key tiles: 2 x 2 sub-problems of 192
   }
   switch (a.nkt) {
     case 2: return launch_fused<2>(a, st);

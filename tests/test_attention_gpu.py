@@ -374,7 +374,7 @@ def test_dropout_streams_are_independent_across_rows_columns_offsets_and_seeds()
 
 # ------------------------------------------------------------------------------------------------ one-pass backward (sam_attn_bwd_fused)
 @pytest.mark.parametrize("shape,spatial", [((3, 20, 100, 50, 12), True), ((3, 20, 100, 50, 12), False), ((4, 20, 0, 0, 0), False), ((2, 5, 30, 20, 7), True),
-                                           ((2, 8, 60, 40, 12), True)])
+                                           ((2, 8, 60, 40, 12), True), ((2, 20, 200, 100, 30), True), ((2, 20, 200, 100, 30), False), ((2, 10, 130, 60, 12), True)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_attention_fused_backward(shape, spatial, p_drop):
     """the training pair sam_attn_fwd_train / sam_attn_bwd_fused (every score computed once, delta from the output and its residual) against the
@@ -430,9 +430,10 @@ def test_attention_fused_backward(shape, spatial, p_drop):
     assert (dk[dead_keys] == 0).all() and (dv[dead_keys] == 0).all()
 
 
-@pytest.mark.parametrize("T", [1, 17, 33, 100, 129, 192])
+@pytest.mark.parametrize("T", [1, 17, 33, 100, 129, 192, 193, 257, 300, 384])
 def test_attention_fused_backward_sequence_length_edges(T):
-    """every key-tile template of the one-pass backward (2, 4, 8, 12 tiles) at and just past its boundaries; key-padding mask, dropout on"""
+    """every key-tile template of the one-pass backward (2, 4, 8, 12 tiles) at and just past its boundaries, and the chunked long-sequence kernel (193 .. 384
+    tokens: 2 x 2 sub-problems of 192, with 8- and 12-word mask rows); key-padding mask, dropout on"""
     ops = _ops()
     B, H, hd = 3, 12, 64
     valid = [T, max(1, T // 2), 1]
