@@ -50,6 +50,101 @@ __device__ __forceinline__ void split_pack8(const float* v, bf16x8& hi, bf16x8& 
 // fma + exp2, the row sum, half a v_cvt_pk_f16_f32 -- and with dropout a packed 16-bit threshold test on the fp16 pairs, the keep-bit
 // word and the counter hash.  Rounds 1-3 spent 23 VALU per score here (hi/lo bf16 split, select-based masks, 32-bit multiplies in the
 // hash); this is ~13 with dropout, ~6 without.
+// one 16-query strip of one (batch, head): scores -> softmax -> dropout -> PV -> stores.  Ks (bf16) / Vs (block-scaled fp16) are the head's LDS tiles.
+template <int NKT, bool DEC, bool DROP>
+__device__ __forceinline__ void attn_fwd_strip(const AttnArgs& a, const unsigned char* Ks, const unsigned char* Vs, const bf16x8 (&qf)[2], const unsigned (&naw)[NKT / 2],
+                                               int bh, int b, int h, int q, int qc, int N, int Dm, int i, int g, float o_unscale, unsigned thr2, unsigned nibmask,
+                                               unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi) {
+  // scores with the mask as the accumulator's initial value: S = -inf wherever the allow bit is clear
+  f32x4 s[NKT];
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    f32x4 acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      acc[r] = __int_as_float(__builtin_amdgcn_sbfe((int)naw[t >> 1], (unsigned)((t & 1) * 16 + r), 1u) & (int)0xff800000u);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc, 0, 0, 0);
+    s[t] = acc;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NKT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
+  mx = xgroup_max(mx);
+  const bool alive = mx > -INFINITY;  // reference: fully masked rows give exactly 0 (sa_m4c.py:574-584)
+  const float bias = (float)P_SHIFT - (alive ? mx : 0.f) * a.scale_log2;
+  float sum = 0.f;
+  unsigned pk[2 * NKT];               // P * 2^14 as fp16 pairs: (keys 4g, 4g+1) and (4g+2, 4g+3) of every tile
+#pragma unroll
+  for (int t = 0; t < NKT; ++t) {
+    float p[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      p[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2, bias));     // 2^14 * exp(scale * s - max); -inf -> 0
+      sum += p[r];
+    }
+    pk[2 * t] = pack_f16x2(p[0], p[1]);
+    pk[2 * t + 1] = pack_f16x2(p[2], p[3]);
+  }
+  sum = xgroup_sum(sum);
+  const unsigned rk = DROP ? attn_row_key((unsigned)(bh * N + qc), off_lo, off_hi, seed_lo, seed_hi) : 0u;
+  // PV, one 32-key slab (two score tiles) at a time: dropout (sa_m4c.py:588: after the row zeroing, before PV) as a packed mask on the fp16
+  // pairs, one MFMA per 16-column block of V
+  const float inv = alive ? o_unscale * __builtin_amdgcn_rcpf(sum) : 0.f;
+  f32x4 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int w = 0; w < NKT / 2; ++w) {
+    typedef __attribute__((ext_vector_type(4))) unsigned u4;
+    u4 pw = {pk[4 * w], pk[4 * w + 1], pk[4 * w + 2], pk[4 * w + 3]};
+    if (DROP) {
+      const u32x4 rn = attn_dropout_bits(rk, (unsigned)(w * 4 + g));
+      const unsigned dm0 = drop_mask16x2(rn.x, thr2), dm1 = drop_mask16x2(rn.y, thr2), dm2 = drop_mask16x2(rn.z, thr2), dm3 = drop_mask16x2(rn.w, thr2);
+      pw[0] &= ~dm0; pw[1] &= ~dm1; pw[2] &= ~dm2; pw[3] &= ~dm3;
+      // keep word of this query row: bit (e>>2)*16 + 4g + (e&3) for the lane's e-th key of the slab (e = 2j / 2j+1 = low / high half of pair j)
+      const unsigned x01 = (dm0 & 0x00020001u) | (dm1 & 0x00080004u), x23 = (dm2 & 0x00020001u) | (dm3 & 0x00080004u);
+      const unsigned dropped = (((x01 | (x01 >> 16)) & 0xFu) | (((x23 | (x23 >> 16)) & 0xFu) << 16)) << (4 * g);
+      const unsigned bits = xgroup_or(nibmask & ~dropped);
+      if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
+    }
+    const f16x8 pa = __builtin_bit_cast(f16x8, pw);
+    bf16x8 vt[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vt[dt] = lds_col_frag(Vs, w, dt, i, g);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(vt[dt]), pa, o[dt], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting every V fragment and hash costs a wave of occupancy
+  }
+  // epilogue, 16 bytes per store: v_permlane16_swap pairs the 4-column fragments of two neighbouring lane groups, lane (i, g) then owns the
+  // eight consecutive columns 32 jp + 16 (g & 1) + 8 (g >> 1) .. +7 of query row i
+  const bool wr = DEC ? (q < N && q >= a.n_enc) : (q < N);
+  const int64_t orow = DEC ? ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm : ((int64_t)b * N + q) * Dm;
+  const int ocol = h * HD + 16 * (g & 1) + 8 * (g >> 1);
+#pragma unroll
+  for (int jp = 0; jp < 2; ++jp) {
+    float v[8];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[2 * jp][r]), __float_as_uint(o[2 * jp + 1][r]), false, false);
+      v[r] = __uint_as_float(sw[0]) * inv;
+      v[4 + r] = __uint_as_float(sw[1]) * inv;
+    }
+    const uint4 hi = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
+    if (wr) {
+      *reinterpret_cast<uint4*>((DEC ? a.out_dec : a.out_w) + orow + ocol + 32 * jp) = hi;
+      if (!DEC && a.out_lo_w)
+        *reinterpret_cast<uint4*>(a.out_lo_w + orow + ocol + 32 * jp) =
+            make_uint4(pack_bf16x2(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x)), pack_bf16x2(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y)),
+                       pack_bf16x2(v[4] - bf_lo(hi.z), v[5] - bf_hi(hi.z)), pack_bf16x2(v[6] - bf_lo(hi.w), v[7] - bf_hi(hi.w)));
+    }
+  }
+  if (!DEC && wr && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx * a.scale_log2 + __builtin_amdgcn_logf(sum) - (float)P_SHIFT : INFINITY;
+}
+
 constexpr int fwd_waves_per_eu(int nkt, int nt) {     // blocks per CU by LDS (2 tiles of nkt * 2 KB) x waves per block / 4 SIMDs, rounded up
   return nkt >= 16 ? 2 : nkt == 12 ? (nt == 512 ? 4 : nt == 384 ? 5 : 3) : nkt == 2 ? 2 : 4;
 }
@@ -127,94 +222,7 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
     for (int w = 0; w < NKT / 2; ++w) naw[w] = ~naw_n[w] >> (4 * g);
     load_strip(mt + NWV);          // (clamped to the last row when there is no next strip)
 
-    // scores with the mask as the accumulator's initial value: S = -inf wherever the allow bit is clear
-    f32x4 s[NKT];
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      f32x4 acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        acc[r] = __int_as_float(__builtin_amdgcn_sbfe((int)naw[t >> 1], (unsigned)((t & 1) * 16 + r), 1u) & (int)0xff800000u);
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_row_frag(Ks, 16 * t + i, 4 * ks + g), qf[ks], acc, 0, 0, 0);
-      s[t] = acc;
-    }
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < NKT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[t][r]);
-    mx = xgroup_max(mx);
-    const bool alive = mx > -INFINITY;  // reference: fully masked rows give exactly 0 (sa_m4c.py:574-584)
-    const float bias = (float)P_SHIFT - (alive ? mx : 0.f) * a.scale_log2;
-    float sum = 0.f;
-    unsigned pk[2 * NKT];               // P * 2^14 as fp16 pairs: (keys 4g, 4g+1) and (4g+2, 4g+3) of every tile
-#pragma unroll
-    for (int t = 0; t < NKT; ++t) {
-      float p[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        p[r] = __builtin_amdgcn_exp2f(fmaf(s[t][r], a.scale_log2, bias));     // 2^14 * exp(scale * s - max); -inf -> 0
-        sum += p[r];
-      }
-      pk[2 * t] = pack_f16x2(p[0], p[1]);
-      pk[2 * t + 1] = pack_f16x2(p[2], p[3]);
-    }
-    sum = xgroup_sum(sum);
-    const unsigned rk = DROP ? attn_row_key((unsigned)(bh * N + qc), off_lo, off_hi, seed_lo, seed_hi) : 0u;
-    // PV, one 32-key slab (two score tiles) at a time: dropout (sa_m4c.py:588: after the row zeroing, before PV) as a packed mask on the fp16
-    // pairs, one MFMA per 16-column block of V
-    const float inv = alive ? o_unscale * __builtin_amdgcn_rcpf(sum) : 0.f;
-    f32x4 o[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) {
-      typedef __attribute__((ext_vector_type(4))) unsigned u4;
-      u4 pw = {pk[4 * w], pk[4 * w + 1], pk[4 * w + 2], pk[4 * w + 3]};
-      if (DROP) {
-        const u32x4 rn = attn_dropout_bits(rk, (unsigned)(w * 4 + g));
-        const unsigned dm0 = drop_mask16x2(rn.x, thr2), dm1 = drop_mask16x2(rn.y, thr2), dm2 = drop_mask16x2(rn.z, thr2), dm3 = drop_mask16x2(rn.w, thr2);
-        pw[0] &= ~dm0; pw[1] &= ~dm1; pw[2] &= ~dm2; pw[3] &= ~dm3;
-        // keep word of this query row: bit (e>>2)*16 + 4g + (e&3) for the lane's e-th key of the slab (e = 2j / 2j+1 = low / high half of pair j)
-        const unsigned x01 = (dm0 & 0x00020001u) | (dm1 & 0x00080004u), x23 = (dm2 & 0x00020001u) | (dm3 & 0x00080004u);
-        const unsigned dropped = (((x01 | (x01 >> 16)) & 0xFu) | (((x23 | (x23 >> 16)) & 0xFu) << 16)) << (4 * g);
-        const unsigned bits = xgroup_or(nibmask & ~dropped);
-        if (q < N && g == (w & 3)) a.keep_w[((int64_t)bh * N + q) * a.NW + w] = bits;
-      }
-      const f16x8 pa = __builtin_bit_cast(f16x8, pw);
-      bf16x8 vt[4];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) vt[dt] = lds_col_frag(Vs, w, dt, i, g);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(as_f16(vt[dt]), pa, o[dt], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);   // keep the slabs sequential: hoisting every V fragment and hash costs a wave of occupancy
-    }
-    // epilogue, 16 bytes per store: v_permlane16_swap pairs the 4-column fragments of two neighbouring lane groups, lane (i, g) then owns the
-    // eight consecutive columns 32 jp + 16 (g & 1) + 8 (g >> 1) .. +7 of query row i
-    const bool wr = DEC ? (q < N && q >= a.n_enc) : (q < N);
-    const int64_t orow = DEC ? ((int64_t)b * (N - a.n_enc) + q - a.n_enc) * Dm : ((int64_t)b * N + q) * Dm;
-    const int ocol = h * HD + 16 * (g & 1) + 8 * (g >> 1);
-#pragma unroll
-    for (int jp = 0; jp < 2; ++jp) {
-      float v[8];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(o[2 * jp][r]), __float_as_uint(o[2 * jp + 1][r]), false, false);
-        v[r] = __uint_as_float(sw[0]) * inv;
-        v[4 + r] = __uint_as_float(sw[1]) * inv;
-      }
-      const uint4 hi = make_uint4(pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7]));
-      if (wr) {
-        *reinterpret_cast<uint4*>((DEC ? a.out_dec : a.out_w) + orow + ocol + 32 * jp) = hi;
-        if (!DEC && a.out_lo_w)
-          *reinterpret_cast<uint4*>(a.out_lo_w + orow + ocol + 32 * jp) =
-              make_uint4(pack_bf16x2(v[0] - bf_lo(hi.x), v[1] - bf_hi(hi.x)), pack_bf16x2(v[2] - bf_lo(hi.y), v[3] - bf_hi(hi.y)),
-                         pack_bf16x2(v[4] - bf_lo(hi.z), v[5] - bf_hi(hi.z)), pack_bf16x2(v[6] - bf_lo(hi.w), v[7] - bf_hi(hi.w)));
-      }
-    }
-    if (!DEC && wr && g == 0) a.lse2_w[(int64_t)bh * N + q] = alive ? mx * a.scale_log2 + __builtin_amdgcn_logf(sum) - (float)P_SHIFT : INFINITY;
+    attn_fwd_strip<NKT, DEC, DROP>(a, Ks, Vs, qf, naw, bh, b, h, q, qc, N, Dm, i, g, o_unscale, thr2, nibmask, seed_lo, seed_hi, off_lo, off_hi);
   }
 }
 
@@ -541,6 +549,102 @@ namespace {
 
 // threads per block: long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU, and
 // run 8 waves (two per SIMD); 12 key tiles (N = 182) run SAM_ATTN_FWD_NT threads (default 512; 384 = two strips per wave, three blocks per CU)
+// ---- 12 key tiles (129 .. 192 tokens: the c3 / c5 shapes), full forward: THREE heads per block, one block per CU ------------------------
+// 768 (batch, head) pairs at two blocks per CU are one and a half rounds: the second round runs half empty (PMC: 42 % of the wave cycles parked),
+// and inside a block twelve strips over eight waves leave four waves idle for half the time.  Here a block of TWELVE waves owns three heads
+// (3 x 48 KB of K / V tiles = 144 KB: the CU's LDS), wave w computes strip w of each head -- one launch round at B = 64, every wave the same work --
+// and the tiles of head j+1 are requested into registers before head j is computed (converted and written to their own LDS region afterwards),
+// so the load phase of a head is covered by the previous head's arithmetic.
+constexpr int FWD3_HEADS = 3;
+template <bool DROP>
+__global__ __launch_bounds__(768) void attn_fwd3_kernel(AttnArgs a) {
+  constexpr int NKT = 12, NPAD = NKT * 16, NT = 768, NWV = 12, PER = NPAD * 8 / NT, TILE = NPAD * ROW_BYTES;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* red = reinterpret_cast<unsigned*>(smem + 2 * FWD3_HEADS * TILE);      // [NWV]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
+  const int N = a.N, Dm = a.H * HD, BH = a.B * a.H;
+  const int64_t ld = 3 * (int64_t)Dm;
+  const int bh0 = blockIdx.x * FWD3_HEADS;
+  const int q = wave * 16 + i, qc = q < N ? q : N - 1;
+
+  uint4 kreg[PER], vreg[PER];
+  bf16x8 qf_n[2];
+  unsigned naw_n[NKT / 2];
+  auto request = [&](int bh) {                 // K / V chunks of the head's tiles, this wave's query rows and allow words (all unconditional, clamped)
+    const int b = bh / a.H, h = bh - b * a.H;
+    const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int c = tid + j * NT, row = c >> 3, ch = c & 7, rc = row < N ? row : N - 1;
+      kreg[j] = *reinterpret_cast<const uint4*>(qbase + Dm + (int64_t)rc * ld + ch * 8);
+      vreg[j] = *reinterpret_cast<const uint4*>(qbase + 2 * Dm + (int64_t)rc * ld + ch * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) qf_n[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
+    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) naw_n[w] = ap[w];
+  };
+  unsigned seed_lo = a.seed_lo, seed_hi = a.seed_hi, off_lo = a.off_lo, off_hi = a.off_hi;
+  if (DROP) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  const unsigned thr2 = ((a.thr16 ^ 0x8000u) & 0xffffu) * 0x00010001u;
+  const unsigned nibmask = 0x000F000Fu << (4 * g);
+
+  request(bh0 < BH ? bh0 : BH - 1);
+#pragma unroll 1
+  for (int j = 0; j < FWD3_HEADS; ++j) {
+    const int bh = bh0 + j;
+    if (bh >= BH) break;                        // (block-uniform)
+    const int b = bh / a.H, h = bh - b * a.H;
+    unsigned char* Ks = smem + (2 * j) * TILE;
+    unsigned char* Vs = Ks + TILE;
+    // ---- the requested tiles: K as it is, V as block-scaled fp16
+    unsigned vmax = 0;
+#pragma unroll
+    for (int x = 0; x < PER; ++x) {
+      const int c = tid + x * NT, row = c >> 3, ch = c & 7;
+      if (row >= N) { kreg[x] = make_uint4(0, 0, 0, 0); vreg[x] = kreg[x]; }
+      *reinterpret_cast<uint4*>(Ks + tile_off(row, ch)) = kreg[x];
+      vmax = absmax_acc4(vmax, vreg[x]);
+    }
+    vmax = wave_max_u32(absmax_fold(vmax));
+    if (lane == 0) red[wave] = vmax;
+    __syncthreads();
+    unsigned bmax = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) bmax = red[w] > bmax ? red[w] : bmax;
+    const int cv = scale_c_of(bmax);
+    const unsigned csub = csub_of(cv);
+#pragma unroll
+    for (int x = 0; x < PER; ++x) {
+      const int c = tid + x * NT;
+      *reinterpret_cast<uint4*>(Vs + tile_off(c >> 3, c & 7)) = bf2h_pk4(vreg[x], csub);
+    }
+    bf16x8 qf[2] = {qf_n[0], qf_n[1]};
+    unsigned naw[NKT / 2];
+#pragma unroll
+    for (int w = 0; w < NKT / 2; ++w) naw[w] = ~naw_n[w] >> (4 * g);
+    __syncthreads();                            // (also: every wave has read red[] before the next head overwrites it)
+    if (j + 1 < FWD3_HEADS && bh + 1 < BH) request(bh + 1);        // in flight while this head is computed
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave * 16 < N)
+      attn_fwd_strip<NKT, false, DROP>(a, Ks, Vs, qf, naw, bh, b, h, q, qc, N, Dm, i, g, ldexpf(a.inv_keep, cv - 112), thr2, nibmask, seed_lo, seed_hi, off_lo, off_hi);
+  }
+}
+
+template <bool DROP>
+int launch_fwd3(const AttnArgs& a, hipStream_t st) {
+  const size_t lds = (size_t)2 * FWD3_HEADS * 12 * 16 * ROW_BYTES + 64;
+  static bool once = false;
+  if (!once) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    once = true;
+  }
+  attn_fwd3_kernel<DROP><<<dim3((a.B * a.H + FWD3_HEADS - 1) / FWD3_HEADS), dim3(768), lds, st>>>(a);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
+
 template <int NKT, bool DEC, bool DROP, int NT>
 int launch_fwd_nt(const AttnArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES + 64;
@@ -579,6 +683,13 @@ int launch_fwd_d(const AttnArgs& a, hipStream_t st) {
 template <bool DEC>
 int launch_fwd_any(const AttnArgs& a, hipStream_t st) {
   const bool drop = !DEC && a.thr16 != 0;
+  if (!DEC && a.nkt == 12 && a.q_begin == 0 && a.B * a.H >= 2 * FWD3_HEADS) {
+    // opt-in: measured 30.5 us against 28.6 us for the one-head blocks (c3, B = 64, dropout on, with the residual output; profiles/r4*_micro_attn.txt):
+    // twelve waves in lock step per CU hide less latency than two independent 8-wave blocks, which costs more than the half-empty second round returns
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("SAM_ATTN_FWD3"); on = (e && e[0] == '1') ? 1 : 0; }
+    if (on) return drop ? launch_fwd3<true>(a, st) : launch_fwd3<false>(a, st);
+  }
 #define SAM_FWD_CASE(K) case K: return drop ? launch_fwd_d<K, DEC, !DEC>(a, st) : launch_fwd_d<K, DEC, false>(a, st);
   switch (a.nkt) {
     SAM_FWD_CASE(2) SAM_FWD_CASE(4) SAM_FWD_CASE(8) SAM_FWD_CASE(12) SAM_FWD_CASE(16) SAM_FWD_CASE(24)

@@ -59,18 +59,27 @@ __device__ __forceinline__ bf16x8 cat4(s16x4 a, s16x4 b) {
   return r;
 }
 
-// reductions across the four 16-lane groups that share (lane & 15)
+// reductions across the four 16-lane groups that share (lane & 15).  v_permlane16_swap / v_permlane32_swap (gfx950) hand every lane its partner's value
+// through the VALU: __shfl_xor compiles to ds_bpermute_b32, an LDS round trip (~100 cycles) on the critical path of every softmax row.
+//   permlane16_swap(v, v) -> {rows 0,0,2,2 | rows 1,1,3,3}: combining the two results reduces over the row pair (lane ^ 16);
+//   permlane32_swap(v, v) -> {lower half twice | upper half twice}: reduces over lane ^ 32.
 __device__ __forceinline__ float xgroup_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16));
-  return fmaxf(v, __shfl_xor(v, 32));
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 __device__ __forceinline__ float xgroup_sum(float v) {
-  v += __shfl_xor(v, 16);
-  return v + __shfl_xor(v, 32);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 __device__ __forceinline__ unsigned xgroup_or(unsigned v) {
-  v |= __shfl_xor(v, 16);
-  return v | __shfl_xor(v, 32);
+  auto a = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+  v = a[0] | a[1];
+  auto b = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  return b[0] | b[1];
 }
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
