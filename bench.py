@@ -76,6 +76,8 @@ def profile_step(trainer, batch, reps=5):
         key = meta.get("kernel", name)
         if key.startswith("gemm<") and meta.get("shape"):
             key += "@M=%d" % meta["shape"][0]             # MMT-size (11648 rows) and TextBert / head-size launches of one symbol are different regimes
+        elif key.startswith("attn_") and meta.get("shape"):
+            key += "@N=%d" % meta["shape"][1]             # 182-token MMT launches vs TextBert's 20-token ones
         a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
         dt = max(statistics.median(r[j][2] for r in runs) - overhead_ms, 0.0)
         a["calls"] += 1
@@ -108,9 +110,14 @@ def pmc_traffic(kernel_key):
         pat8 = re.compile(r"gemm8_kernel<\d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
         sel = [v for k, v in kern.items() if pat.match(k) or pat8.match(k)]
     else:
-        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel"],
-                 "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel"]}.get(kernel_key, [kernel_key.replace("sam_", "")])
-        sel = [v for k, v in kern.items() if any(k.startswith(n) for n in names)]
+        base, _, n_tok = kernel_key.partition("@N=")
+        names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel", "attn_bwd_fused_long_kernel"],
+                 "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel"]}.get(base, [base.replace("sam_", "")])
+        sel = [(k, v) for k, v in kern.items() if any(k.startswith(n) for n in names)]
+        if n_tok:      # attention kernels are templated on the number of 16-key tiles: keep the instantiation this sequence length runs
+            nkt = next(t for t in (2, 4, 8, 12, 16, 24) if t * 16 >= int(n_tok))
+            sel = [(k, v) for k, v in sel if re.search(r"<%d[,>]" % nkt, k) or "long_kernel" in k or "dkdv" in k]
+        sel = [v for _, v in sel]
     n = sum(v["launches_profiled"] for v in sel)
     if not n:
         return None
@@ -160,8 +167,9 @@ def roofline_from(agg):
         roof = dict(kernel=top["kernel"], bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
                     traffic=pmc_traffic(top["kernel"]), avg_launch_us=top["avg_us"], launches_per_step=a["calls"], bytes_per_launch=a["bytes"] / a["calls"])
     extra = {}
-    for key in ("attn_fwd", "attn_bwd(fused)", "attn_bwd(dq+dkdv)"):     # the north-star kernel: HBM-bound, reported next to the dominant (GEMM) kernel
-        if key in agg and agg[key]["bytes"]:
+    attn_keys = sorted((k for k in agg if k.startswith("attn_") and agg[k]["bytes"]), key=lambda k: -agg[k]["ms"])
+    for key in attn_keys[:4]:     # the north-star kernel (per sequence length): HBM-bound, reported next to the dominant (GEMM) kernel
+        if True:
             a = agg[key]
             ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
             extra[key] = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
