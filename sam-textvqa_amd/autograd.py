@@ -466,6 +466,11 @@ class DeferredWgrads:
             cls.flush()
         cls.jobs, cls.acc = cls.jobs + list(jobs), acc
         cls.layers.append(layer)
+        # MMT layers go out in PAIRS (modules.SAM4C marks them `_sam_defer_flush_at = 2`): two layers are 216 tiles of 256 x 256 -- one launch round with
+        # the K range of every tile whole, i.e. no pair exchange and no second block per tile, instead of twice 108 tiles x 2 k-halves
+        limit = getattr(layer, "_sam_defer_flush_at", None)
+        if limit and len(cls.layers) >= limit:
+            cls.flush()
 
     @classmethod
     def flush(cls):

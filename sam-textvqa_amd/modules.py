@@ -617,6 +617,7 @@ class SAM4C(_HipModule):
         self.text_bert = TextBert(text_bert_config)
         for layer in self.text_bert.encoder.layer:
             layer._sam_defer_wgrad = True               # their weight gradients go out together, in one grouped launch (autograd.DeferredWgrads)
+        self._mmt_wgrad_pairs = int(os.environ.get("SAM_DEFER_MMT_WGRAD", "0"))
         if getattr(text_bert_config, "text_bert_init_from_bert_base", False):
             # sa_m4c.py:74-85: TextBert starts from bert-base-uncased and trains at lr_scale_text_bert x the base rate (its own optimizer group,
             # BEFORE the MMT group).  The reference downloads the weights; here they come from a local file / directory
@@ -641,6 +642,12 @@ class SAM4C(_HipModule):
         self.ocr_bbox_layer_norm = BertLayerNorm(h)
         self.ocr_drop_p = mmt_config.ocr_drop
         self.mmt = MMT(mmt_config)
+        if self._mmt_wgrad_pairs >= 2:
+            # weight gradients of the MMT layers in groups of `_mmt_wgrad_pairs` layers per launch (backward order); a last incomplete group is flushed by the Trainer's join
+            enc = self.mmt.encoder
+            for layer in list(getattr(enc, "normal_layers", [])) + list(getattr(enc, "spatial_layers", [])):
+                layer._sam_defer_wgrad = True
+                layer._sam_defer_flush_at = self._mmt_wgrad_pairs
         self.finetune_modules.append({"module": self.mmt, "lr_scale": mmt_config.lr_scale_mmt})
         self.ocr_ptr_net = OcrPtrNet(hidden_size=h, query_key_size=mmt_config.ptr_query_size)
         n_out = num_answers if num_answers is not None else len(registry.answer_vocab)
