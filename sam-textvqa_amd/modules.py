@@ -617,7 +617,7 @@ class SAM4C(_HipModule):
         self.text_bert = TextBert(text_bert_config)
         for layer in self.text_bert.encoder.layer:
             layer._sam_defer_wgrad = True               # their weight gradients go out together, in one grouped launch (autograd.DeferredWgrads)
-        self._mmt_wgrad_pairs = int(os.environ.get("SAM_DEFER_MMT_WGRAD", "0"))
+        self._mmt_wgrad_pairs = int(os.environ.get("SAM_DEFER_MMT_WGRAD", "2"))
         if getattr(text_bert_config, "text_bert_init_from_bert_base", False):
             # sa_m4c.py:74-85: TextBert starts from bert-base-uncased and trains at lr_scale_text_bert x the base rate (its own optimizer group,
             # BEFORE the MMT group).  The reference downloads the weights; here they come from a local file / directory
