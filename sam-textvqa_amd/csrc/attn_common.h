@@ -83,28 +83,11 @@ __device__ __forceinline__ uint4 bf2h_pk4(uint4 v, unsigned csub) {
   return make_uint4(bf2h_pk(v.x, csub), bf2h_pk(v.y, csub), bf2h_pk(v.z, csub), bf2h_pk(v.w, csub));
 }
 
-// ---- attention-probability dropout: 8 x 16 random bits per (row, 32-key slab, lane group) ----------------------------------------------
-// Rounds 1-3 drew them with dropout_bits128 (common.h): 13 quarter-rate 32-bit multiplies per draw, a fifth of the forward's VALU time.
-// Here the expensive mixing happens once per query row (row_key); a draw then costs full-rate operations only: two 24-bit multiplies per
-// 32-bit word (v_mul_u32_u24 / v_mad_u32_u24) around xor-shifts.  Statistics (keep rate, independence across rows / keys / heads /
-// samples / offsets / seeds, avalanche, duplicate census) checked on the CPU against the old generator: tools/debug/hash_eval.py.
+// ---- attention-probability dropout: 8 x 16 random bits per (row, 32-key slab, lane group): dropout_row_key / dropout_bits_fast of common.h
 __device__ __forceinline__ unsigned attn_row_key(unsigned row, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {
-  return mix32(row * 0x9E3779B1u + (off_lo ^ seed_lo)) ^ (off_hi * 0xC2B2AE3Du + seed_hi);
+  return dropout_row_key(row, off_lo, off_hi, seed_lo, seed_hi);
 }
-__device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }
-__device__ __forceinline__ u32x4 attn_dropout_bits(unsigned row_key, unsigned col_group) {
-  const unsigned x = row_key + col_group * 0x85EBCA77u;
-  const unsigned t = x ^ (x >> 15), tb = t >> 11;
-  u32x4 r;
-  unsigned y;
-#define SAM_FIN24(c1, d1) (y = mul24(t, c1) + mul24(tb, d1), y ^= y >> 13, y = mul24(y, 0x52A6B5u), y ^ (y >> 16))
-  r.x = SAM_FIN24(0x6B43A9u, 0x3C6EF3u);
-  r.y = SAM_FIN24(0xD35A2Du, 0x7F4A7Du);
-  r.z = SAM_FIN24(0x9E3B71u, 0x2545F5u);
-  r.w = SAM_FIN24(0xB5297Bu, 0x5851F5u);
-#undef SAM_FIN24
-  return r;
-}
+__device__ __forceinline__ u32x4 attn_dropout_bits(unsigned row_key, unsigned col_group) { return dropout_bits_fast(row_key, col_group); }
 // dropped-lane mask of a random word: each 16-bit half becomes 0xFFFF iff its value < thr16 (thr2 = (thr16 ^ 0x8000) in both halves)
 __device__ __forceinline__ unsigned drop_mask16x2(unsigned rnd, unsigned thr2) {
   i16x2 d = __builtin_elementwise_sub_sat(__builtin_bit_cast(i16x2, rnd ^ 0x80008000u), __builtin_bit_cast(i16x2, thr2));

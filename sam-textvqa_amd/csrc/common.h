@@ -122,14 +122,34 @@ __device__ __forceinline__ u32x4 dropout_bits128(unsigned c0, unsigned c1, unsig
   const unsigned base = mix32(c0 * 0x9E3779B1u + (c2 ^ k0)) ^ (c1 * 0x85EBCA77u + c3 * 0xC2B2AE3Du + k1);
   return {mix32(base), mix32(base + 0x68E31DA4u), mix32(base + 0xB5297A4Du), mix32(base + 0x1B56C4E9u)};
 }
+// Round-4 generator: the expensive mixing (mix32: two 32-bit multiplies) happens once per ROW (dropout_row_key; loop-invariant wherever a thread or wave stays
+// on one row: the attention strips, the LayerNorm backward, the GEMM epilogue's row loop); a draw of 8 x 16 bits for (row, column group) then costs full-rate
+// operations only -- two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24) around xor-shifts per 32-bit word.  dropout_bits128 above spends 13 quarter-rate
+// 32-bit multiplies per draw: a fifth of the attention forward's VALU time, 3 us of a 17 us LayerNorm backward.  Keep rate, independence across rows / columns /
+// heads / samples / offsets / seeds, avalanche and a duplicate census were checked on the CPU against the old generator (tools/debug/hash_eval.py) and are
+// tested on the device (tests/test_attention_gpu.py::test_dropout_streams_are_independent_...).
+__device__ __forceinline__ unsigned dropout_row_key(unsigned row, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {
+  return mix32(row * 0x9E3779B1u + (off_lo ^ seed_lo)) ^ (off_hi * 0xC2B2AE3Du + seed_hi);
+}
+__device__ __forceinline__ u32x4 dropout_bits_fast(unsigned row_key, unsigned col_group) {
+  const unsigned x = row_key + col_group * 0x85EBCA77u;
+  const unsigned t = x ^ (x >> 15), tb = t >> 11;
+  u32x4 r;
+  unsigned y;
+#define SAM_FIN24(c1, d1) (y = __umul24(t, c1) + __umul24(tb, d1), y ^= y >> 13, y = __umul24(y, 0x52A6B5u), y ^ (y >> 16))
+  r.x = SAM_FIN24(0x6B43A9u, 0x3C6EF3u);
+  r.y = SAM_FIN24(0xD35A2Du, 0x7F4A7Du);
+  r.z = SAM_FIN24(0x9E3B71u, 0x2545F5u);
+  r.w = SAM_FIN24(0xB5297Bu, 0x5851F5u);
+#undef SAM_FIN24
+  return r;
+}
 // Hidden-state dropout (GEMM epilogues of BertSelfOutput / BertOutput, regenerated by the LayerNorm backward; the embedding dropout of
-// PrevPredEmbeddings): 8 x 16 random bits per (row, 8-column group).  Philox4x32-10 here cost as much VALU as an erf-GELU per element
-// (20 quarter-rate integer multiplies per call: +4..15 us on every dropout epilogue, +6 us on each LayerNorm backward); the counter hash
-// above draws the same 128 bits for a third of the instructions.
+// PrevPredEmbeddings; the input encoders): 8 x 16 random bits per (row, 8-column group).
 __device__ __forceinline__ u32x4 hidden_dropout_bits(unsigned row, unsigned col8, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {
   // (domain separation: the key is flipped by a constant so that a hidden-state site and an attention site never draw the same 128 bits even
   // when handed the same (seed, offset) -- without it the two masks agreed 4.6 % more often than independent draws)
-  return dropout_bits128(row, col8, off_lo, off_hi, seed_lo ^ 0x5bd1e995u, seed_hi ^ 0x1b873593u);
+  return dropout_bits_fast(dropout_row_key(row, off_lo, off_hi, seed_lo ^ 0x5bd1e995u, seed_hi ^ 0x1b873593u), col8);
 }
 // dropout threshold on 16-bit lanes of the random words: element kept iff rnd16 >= thr16
 __host__ __device__ __forceinline__ unsigned dropout_thr16(float p) {

@@ -98,3 +98,22 @@ for nm, fn in (("fin24s", new_s), ("fin24t", new_t), ("current", cur)):
     key = (w[0] << np.uint64(32)) | w[1]
     n = key.size; nu = np.unique(key).size
     print(nm, "draws", n, "distinct 64-bit prefixes", nu, "duplicates", n - nu)
+
+
+def hidden_report(name, fn, M_=4096, D=768, thr=6554):
+    """the hidden-state layout: one draw per (row, 8-column group), fields e = column within the group (tests/test_attention_gpu.py hidden-state checks)"""
+    p = 0.1; indep = p * p + (1 - p) ** 2
+    def mask(seed, offset):
+        row = np.arange(M_)[:, None]; c8 = np.arange(D // 8)[None, :]
+        F = fields(fn(row + 0 * c8, c8 + 0 * row, offset & 0xFFFFFFFF, offset >> 32, (seed & 0xFFFFFFFF) ^ 0x5bd1e995, (seed >> 32) ^ 0x1b873593))   # [M, D/8, 8]
+        return (F >= thr).reshape(M_, D)
+    h0 = mask(3, 9)
+    res = {"mean": h0.mean() - 0.9, "row+1": agree(h0[:-1], h0[1:]) - indep, "col+1": agree(h0[:, :-1], h0[:, 1:]) - indep, "col+8": agree(h0[:, :-8], h0[:, 8:]) - indep,
+           "row+256": agree(h0[:-256], h0[256:]) - indep, "off+1": agree(h0, mask(3, 10)) - indep, "seed+1": agree(h0, mask(4, 9)) - indep,
+           "off+2^32": agree(h0, mask(3, 9 + (1 << 32))) - indep, "colrate": np.abs(h0.mean(0) - 0.9).max(), "rowrate": np.abs(h0.mean(1) - 0.9).max()}
+    # against the attention stream under the same (seed, offset): keep_tensor flips nothing, hidden flips the key -> independent
+    print("hidden", name, " ".join("%s=%+.4f" % kv for kv in res.items()))
+
+
+hidden_report("current", cur)
+hidden_report("fin24t", new_t)
