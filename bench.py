@@ -468,6 +468,12 @@ def main():
         parallel.dist.barrier()
     torch.cuda.synchronize()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # the cyclic collector stays off inside the timed region (a generation-2 pass over the model's object graph is a 10-20 ms host pause, i.e. two or three
+    # steps of an idle GPU once every few hundred steps: seen as single 20 ms steps in `slow_steps`); a training loop does the same with gc.freeze()
+    import gc
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     for j in range(args.steps):
@@ -478,6 +484,8 @@ def main():
         parallel.dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if gc_was_on:
+        gc.enable()
     step_ms = [marks[j].elapsed_time(marks[j + 1]) for j in range(args.steps)]
     if parallel.dist.is_initialized():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -500,6 +508,8 @@ def main():
                    "global_batch": gb, "per_gpu_batch": args.batch, "seq_len": sum(shape), "parallelism": "dp%d" % world},
         "final_loss": final_loss,
         "ms_per_step_median": round(statistics.median(step_ms), 3),           # GPU time between per-step events on the launch stream (the value above is the wall-clock mean)
+        "ms_per_step_p10_p90_max": [round(sorted(step_ms)[len(step_ms) // 10], 3), round(sorted(step_ms)[(9 * len(step_ms)) // 10], 3), round(max(step_ms), 3)],
+        "slow_steps": [[j, round(t, 2)] for j, t in enumerate(step_ms) if t > 1.15 * statistics.median(step_ms)][:12],
         "batches_rotated": len(rot),
         "word_table_rows_touched": int(trainer.sparse[3].sum().item()) if getattr(trainer, "sparse", None) is not None else None,
         "train_gflop_per_sample": round(train_gflop(shape, len(layers), args.vocab), 2),
