@@ -109,7 +109,8 @@ def test_torch_custom_ops_build_and_register_without_a_gpu():
     """csrc_torch/sam_torch_ops.cpp: TORCH_LIBRARY(sam_hip) schemas are visible to the dispatcher after load; running them needs the GPU"""
     from sam_textvqa_amd import torchops
     ns = torchops.ns()
-    for op in ("linear", "spatial_attn_fwd", "spatial_attn_bwd", "layernorm_fwd", "layernorm_bwd", "encoder_layer_fwd", "encoder_layer_bwd"):
+    for op in ("linear", "spatial_attn_fwd", "spatial_attn_bwd", "spatial_attn_fwd_train", "spatial_attn_bwd_fused", "layernorm_fwd", "layernorm_bwd", "encoder_layer_fwd",
+               "encoder_layer_bwd"):
         assert hasattr(ns, op), op
     schema = str(torch.ops.sam_hip.encoder_layer_fwd.default._schema)
     assert "Tensor[] params" in schema and "int[] seeds" in schema
