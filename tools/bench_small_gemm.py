@@ -11,7 +11,7 @@ def t(fn, n=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
 def rnd(*s): return torch.randn(*s, device="cuda").to(torch.bfloat16)
-for name, M, N, K, bk in [("TB ffn2 fwd", 1280, 768, 3072, True), ("TB ffn1 dgrad", 1280, 768, 3072, False), ("TB qkv dgrad", 1280, 768, 2304, False),
+for name, M, N, K, bk in [("TB qkv fwd", 1280, 2304, 768, True), ("TB ffn1 fwd", 1280, 3072, 768, True), ("TB ffn2 dgrad", 1280, 3072, 768, False), ("TB ffn2 fwd", 1280, 768, 3072, True), ("TB ffn1 dgrad", 1280, 768, 3072, False), ("TB qkv dgrad", 1280, 768, 2304, False),
                           ("TB o-proj fwd", 1280, 768, 768, True), ("cls dgrad", 768, 768, 5000, False), ("ocr proj", 3200, 768, 3008, True),
                           ("obj proj", 6400, 768, 2048, True)]:
     a = rnd(M, K); b = rnd(N, K) if bk else rnd(K, N)
