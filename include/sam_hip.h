@@ -273,6 +273,16 @@ int sam_adam_step(float* p, float* g, float* m, float* v, void* p_bf16, int64_t 
  * captured in a hipGraph freezes its by-value arguments; this form lets every replay apply the current learning rates / bias corrections. */
 int sam_adam_step_dev(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
                       float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream);
+/* sam_adam_step_dev restricted to the elements [lo, hi) of the buffers (multiples of 4; the row-sparse region entirely inside or outside), for a step
+ * whose update is applied in pieces on several streams: the pending update of step k at the HEAD of captured step k + 1, where the piece the next
+ * forward needs first (TextBert, the input encoders) goes out before the rest and the rest runs underneath that forward (same train.py:139-142
+ * arithmetic, element for element; seg_end / dev_sched describe the WHOLE buffer).  zero_grad != 0: every gradient element is cleared after use (the
+ * step then needs no zero-fill and no ordering between it and the pieces).  gate (may be NULL): device word; 0 = the launch does nothing -- a replay
+ * whose pending update the host has already applied (Trainer.flush_update) skips it that way.  max_blocks > 0 caps the grid (a piece that runs
+ * underneath latency-bound work must leave wave slots free for it; 0 = the full-speed grid). */
+int sam_adam_step_range(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                        float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, int64_t lo, int64_t hi,
+                        int zero_grad, const int32_t* gate, int max_blocks, void* stream);
 /* Per-step state of a hipGraph-captured training step, advanced ON THE DEVICE by the graph's first node (nothing the host writes is read by
  * a replay, so the host may queue replays as far ahead as it likes):
  *   rng_state[1] += offset_stride (fresh dropout masks; rng_state = the array given to sam_set_rng_state, may be NULL);

@@ -65,6 +65,7 @@ SIGNATURES = {
     "sam_sumsq_f32": [_vp, _i64, C.c_void_p, _vp, _vp, _vp],
     "sam_adam_step": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), C.POINTER(_f), _i, _f, _f, _f, _i64, _vp, _f, C.c_void_p, _vp],
     "sam_adam_step_dev": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, C.c_void_p, _vp],
+    "sam_adam_step_range": [_vp, _vp, _vp, _vp, _vp, _i64, C.POINTER(_i64), _i, _f, _f, _f, _vp, _vp, _f, C.c_void_p, _i64, _i64, _i, _vp, _i, _vp],
     "sam_cast_f32_to_bf16": [_vp, _vp, _i64, _vp],
     "sam_pack_masks_u8": [_vp, _i, _vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "sam_add_dropout_bf16": [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _f, _u64, _u64, _vp],

@@ -457,6 +457,7 @@ class DeferredWgrads:
     to 12 problems when the embedding block below them starts its backward (EmbedLayerNormFn) -- or, failing that, when the Trainer joins the backward.
     Their data-parallel regions are reported done after that launch, in backward order."""
     jobs, layers, acc = [], [], None
+    late_stream, late = None, []
 
     @classmethod
     def add(cls, layer, jobs, acc):
@@ -470,21 +471,51 @@ class DeferredWgrads:
         # the K range of every tile whole, i.e. no pair exchange and no second block per tile, instead of twice 108 tiles x 2 k-halves
         limit = getattr(layer, "_sam_defer_flush_at", None)
         if limit and len(cls.layers) >= limit:
-            cls.flush()
+            cls.flush(late=bool(getattr(layer, "_sam_wgrad_late", False)))
 
     @classmethod
-    def flush(cls):
+    def flush(cls, late=False):
         if not cls.jobs:
             return
         jobs, layers, acc = cls.jobs, cls.layers, cls.acc
         cls.jobs, cls.layers, cls.acc = [], [], None
+        if late and jobs[0][0].is_cuda and wgrad_late_enabled():
+            # the group that closes the MMT's backward (its first layers): nothing on the rest of the backward path reads these weight gradients, and what
+            # follows on the issuing stream is the tail's chain of small kernels (embedding blocks, object / OCR encoders, TextBert's 1280-row layers).
+            # The ~0.3 ms launch runs on a stream of its own next to that chain instead of in front of it; Trainer joins it before the gradient norm.
+            if parallel.active_reducer is not None and ops.LnFinalizeQueue.defer:     # (the layers' LayerNorm partial sums: finalized where they were written)
+                ops.LnFinalizeQueue.flush()
+                if torchops.enabled():
+                    torchops.ns().ln_finalize_flush()
+            cur = torch.cuda.current_stream()
+            if cls.late_stream is None:
+                cls.late_stream = torch.cuda.Stream()
+            cls.late_stream.wait_stream(cur)
+            with torch.cuda.stream(cls.late_stream):
+                ops.wgrad_grouped(jobs, accumulate=acc)
+                for layer in layers:
+                    region_done(getattr(layer, "_sam_region_id", None))
+            cls.late.append(jobs)                 # operands were allocated on the issuing stream: alive until join()
+            return
         ops.wgrad_grouped(jobs, accumulate=acc)
         for layer in layers:
             region_done(getattr(layer, "_sam_region_id", None))
 
     @classmethod
+    def join(cls):
+        """the current stream waits for a weight-gradient launch that went to the side (flush(late=True))"""
+        if cls.late:
+            torch.cuda.current_stream().wait_stream(cls.late_stream)
+            cls.late = []
+
+    @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
+        cls.late = []
+
+
+def wgrad_late_enabled():
+    return os.environ.get("SAM_WGRAD_LATE", "1") != "0"
 
 
 def defer_wgrad_enabled():

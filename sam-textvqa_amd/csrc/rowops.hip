@@ -496,7 +496,10 @@ struct AdamSegs { int64_t end[8]; float lr[8]; int n; };
 // schedule of the current step from there instead of from its frozen by-value arguments
 __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m, float* v, bf16_t* pb, int64_t n, AdamSegs segs, float b1, float b2,
                                                    float eps, float bc1, float rsqrt_bc2, const float* gnorm_sq, float max_norm, const float* dev_sched, SparseRows sp,
-                                                   int dense_blocks) {
+                                                   int dense_blocks, int64_t jlo, int64_t jhi, int zero_g, const int* gate) {
+  // [jlo, jhi): this launch's share of the dense index space (all float4 outside the row-sparse region); gate: a device word -- 0 = do nothing
+  // (sam_adam_step_range: the pending update at the head of a captured step, which a replay must skip when the host has already applied it)
+  if (gate && *gate == 0) return;
   if (dev_sched) {
     for (int s = 0; s < segs.n; ++s) segs.lr[s] = dev_sched[s];
     bc1 = dev_sched[segs.n];
@@ -504,17 +507,17 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
   }
   float clip = 1.0f;
   if (gnorm_sq && max_norm > 0.f) clip = fminf(1.0f, max_norm / (sqrtf(gnorm_sq[0]) + 1e-6f));   // torch clip_grad_norm_
-  const int64_t n4 = n >> 2, gap = sp.hi4 - sp.lo4;
+  const int64_t gap = sp.hi4 - sp.lo4;
   const bool row_block = (int)blockIdx.x >= dense_blocks;
   // dense blocks: every float4 outside the row-sparse region; row blocks: the touched rows of that region, one wave per row -- whose gradient is
   // cleared on the way out (the region is not zero-filled per step: untouched rows stay zero for ever)
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int row = row_block ? ((int)blockIdx.x - dense_blocks) * 4 + wave : 0, c = lane;
   if (row_block) { while (row < sp.rows && !sp.touched[row]) row += SPARSE_ROW_BLOCKS * 4; }
-  for (int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;; j += (int64_t)dense_blocks * 256) {
+  for (int64_t j = jlo + (int64_t)blockIdx.x * 256 + threadIdx.x;; j += (int64_t)dense_blocks * 256) {
     int64_t i;
     if (!row_block) {
-      if (j >= n4 - gap) break;
+      if (j >= jhi) break;
       i = j < sp.lo4 ? j : j + gap;
     } else {
       if (row >= sp.rows) break;
@@ -545,8 +548,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, float* g, float* m,
     __builtin_nontemporal_store((v4f){mm[0], mm[1], mm[2], mm[3]}, reinterpret_cast<v4f*>(m) + i);
     __builtin_nontemporal_store((v4f){vv[0], vv[1], vv[2], vv[3]}, reinterpret_cast<v4f*>(v) + i);
     if (pb) reinterpret_cast<uint2*>(pb)[i] = make_uint2(pack_bf16x2(pp[0], pp[1]), pack_bf16x2(pp[2], pp[3]));
+    if (row_block || zero_g) reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (row_block) {
-      reinterpret_cast<float4*>(g)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       c += 64;
       if (c >= sp.row_len4) {
         c = lane;
@@ -781,7 +784,8 @@ extern "C" int sam_sumsq_f32(const float* g, int64_t n, const sam_sparse_rows* s
 }
 
 static int adam_launch(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, const float* seg_lr, int nseg, float beta1,
-                       float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const float* dev_sched, const sam_sparse_rows* sparse, void* stream) {
+                       float beta2, float eps, int64_t step, const float* gnorm_sq, float max_norm, const float* dev_sched, const sam_sparse_rows* sparse, void* stream,
+                       int64_t lo = 0, int64_t hi = -1, int zero_g = 0, const int* gate = nullptr, int max_blocks = 0) {
   SAM_REQUIRE(p && g && m && v && seg_end && (seg_lr || dev_sched), "sam_adam_step: null pointer");
   SAM_REQUIRE(n > 0 && n % 4 == 0 && nseg >= 1 && nseg <= 8 && (step >= 1 || dev_sched), "sam_adam_step: need n %% 4 == 0, 1..8 segments, step >= 1");
   AdamSegs segs = {};
@@ -795,9 +799,19 @@ static int adam_launch(float* p, float* g, float* m, float* v, void* p_bf16, int
   const float bc2 = 1.0f - powf(beta2, (float)(step >= 1 ? step : 1));
   SparseRows sp;
   if (int rc = fill_sparse(sp, sparse, n)) return rc;
-  const int dense = (int)min((int64_t)4096, ((n >> 2) + 255) / 256), blocks = dense + (sp.touched ? SPARSE_ROW_BLOCKS : 0);
+  // the launch's range [lo, hi) of the buffer: the row-sparse region lies inside it (its touched rows are walked) or outside (they are not)
+  if (hi < 0) hi = n;
+  SAM_REQUIRE(lo >= 0 && lo < hi && hi <= n && lo % 4 == 0 && hi % 4 == 0, "sam_adam_step: range [lo, hi) must be a non-empty multiple-of-4 piece of [0, n)");
+  const int64_t lo4 = lo >> 2, hi4 = hi >> 2, gap = sp.hi4 - sp.lo4;
+  const bool rows_inside = sp.touched && lo4 <= sp.lo4 && sp.hi4 <= hi4;
+  SAM_REQUIRE(!sp.touched || rows_inside || hi4 <= sp.lo4 || lo4 >= sp.hi4, "sam_adam_step: the range may not cut the row-sparse region");
+  const int64_t jlo = lo4 <= sp.lo4 ? lo4 : lo4 - gap, jhi = hi4 <= sp.lo4 ? hi4 : hi4 - gap;      // the same range in the dense index space
+  if (!rows_inside) sp.touched = nullptr, sp.rows = 0;
+  // max_blocks: a piece that runs UNDERNEATH other work keeps to a few blocks per CU -- 4096 grid-stride blocks fill every wave slot of the GPU for the
+  // whole launch and the small kernels beside it wait for them to retire
+  const int dense = (int)max((int64_t)1, min((int64_t)(max_blocks > 0 ? max_blocks : 4096), (jhi - jlo + 255) / 256)), blocks = dense + (sp.touched ? SPARSE_ROW_BLOCKS : 0);
   adam_kernel<<<dim3(blocks), dim3(256), 0, (hipStream_t)stream>>>(p, g, m, v, (bf16_t*)p_bf16, n, segs, beta1, beta2, eps, bc1, 1.0f / sqrtf(bc2), gnorm_sq, max_norm,
-                                                                   dev_sched, sp, dense);
+                                                                   dev_sched, sp, dense, jlo, jhi, zero_g, gate);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -809,6 +823,14 @@ extern "C" int sam_adam_step_dev(float* p, float* g, float* m, float* v, void* p
                                  float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, void* stream) {
   SAM_REQUIRE(dev_sched, "sam_adam_step_dev: null schedule");
   return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, sparse, stream);
+}
+
+extern "C" int sam_adam_step_range(float* p, float* g, float* m, float* v, void* p_bf16, int64_t n, const int64_t* seg_end, int nseg, float beta1, float beta2,
+                                   float eps, const float* dev_sched, const float* gnorm_sq, float max_norm, const sam_sparse_rows* sparse, int64_t lo, int64_t hi,
+                                   int zero_grad, const int32_t* gate, int max_blocks, void* stream) {
+  SAM_REQUIRE(dev_sched && max_blocks >= 0, "sam_adam_step_range: null schedule");
+  return adam_launch(p, g, m, v, p_bf16, n, seg_end, nullptr, nseg, beta1, beta2, eps, 0, gnorm_sq, max_norm, dev_sched, sparse, stream, lo, hi, zero_grad, gate,
+                     max_blocks);
 }
 
 // Head node of a captured (hipGraph) training step: everything that changes from replay to replay and used to be a by-value argument lives in

@@ -496,6 +496,9 @@ class MMT(_HipModule):
 
     def forward(self, batch_dict, fixed_ans_emb):
         self._ready()
+        ev = batch_dict.pop("_sam_upd_event", None)
+        if ev is not None:                                # the MMT's piece of the previous step's update ran on its own stream (Trainer._issue_pending_update)
+            torch.cuda.current_stream().wait_event(ev)
         dec_emb = self.prev_pred_embeddings(fixed_ans_emb, batch_dict["ocr_mmt_in"], batch_dict["train_prev_inds"])
         ev = batch_dict.pop("_sam_tb_event", None)
         if ev is not None:                                # TextBert ran on a side stream (SAM4C.forward): join it here, as late as possible
@@ -648,6 +651,10 @@ class SAM4C(_HipModule):
             for layer in list(getattr(enc, "normal_layers", [])) + list(getattr(enc, "spatial_layers", [])):
                 layer._sam_defer_wgrad = True
                 layer._sam_defer_flush_at = self._mmt_wgrad_pairs
+            if len(enc.layer_type_list) % self._mmt_wgrad_pairs == 0:
+                # the group that the FIRST layer (last in the backward) closes runs beside the tail of the backward, not in front of it (DeferredWgrads.flush)
+                first = (enc.normal_layers if enc.layer_type_list[0] == "n" else enc.spatial_layers)[0]
+                first._sam_wgrad_late = True
         self.finetune_modules.append({"module": self.mmt, "lr_scale": mmt_config.lr_scale_mmt})
         self.ocr_ptr_net = OcrPtrNet(hidden_size=h, query_key_size=mmt_config.ptr_query_size)
         n_out = num_answers if num_answers is not None else len(registry.answer_vocab)

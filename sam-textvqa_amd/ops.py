@@ -549,6 +549,18 @@ def adam_step_dev(p, g, m, v, p_bf16, seg_end, dev_sched, gnorm_sq=None, max_nor
               float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), sp, capi.stream_handle())
 
 
+def adam_step_range(p, g, m, v, p_bf16, seg_end, dev_sched, lo, hi, gnorm_sq=None, max_norm=0.0, betas=(0.9, 0.999), eps=1e-8, sparse=None, zero_grad=True, gate=None,
+                    max_blocks=0):
+    """adam_step_dev over the elements [lo, hi) only (sam_adam_step_range): the update in pieces, each on the stream that needs it; `zero_grad`: the piece's
+    gradient is cleared after use; `gate`: int32 device scalar, 0 = the launch does nothing"""
+    import ctypes as C
+    n = len(seg_end)
+    ends = (C.c_int64 * n)(*[int(e) for e in seg_end])
+    sp, keep = _sparse_struct(sparse)          # (the row-sparse region is walked by the piece that contains it)
+    capi.call("sam_adam_step_range", capi.ptr(p), capi.ptr(g), capi.ptr(m), capi.ptr(v), capi.ptr(p_bf16), p.numel(), ends, n, float(betas[0]), float(betas[1]),
+              float(eps), capi.ptr(dev_sched), capi.ptr(gnorm_sq), float(max_norm), sp, int(lo), int(hi), int(bool(zero_grad)), capi.ptr(gate), int(max_blocks), capi.stream_handle())
+
+
 def copy_blocks(blocks):
     """up to 8 strided copies / casts / accumulations / zero-fills in one launch (sam_copy_blocks).  Each block: (src | None, dst, accumulate=False) with
     src / dst 3-D views [batches, rows, cols] (any batch / row stride, unit column stride, bf16 or fp32); src None fills dst with zeros."""

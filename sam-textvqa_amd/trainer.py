@@ -29,7 +29,8 @@ def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, global_count=No
 
 
 class Trainer:
-    def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0, use_graph=None):
+    def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0, use_graph=None,
+                 pipeline_update=None):
         self.model = model
         self.base_lr = base_lr
         groups = model.get_optimizer_parameters(base_lr)
@@ -83,7 +84,26 @@ class Trainer:
         self.global_step = 0
         self.epoch_id, self.current_val_score = 0, None
         self.use_graph = bool(use_graph) if use_graph is not None else os.environ.get("SAM_STEP_GRAPH", "0") == "1"
-        self._graph, self._graph_sig, self._graph_warm = None, None, False
+        self._graph, self._graph_sig, self._graph_warm, self._pipelined_graph = None, None, False, False
+        # Captured steps only: clip + Adam of step k are the FIRST nodes of replay k + 1 instead of the last of replay k -- in two pieces: what the head of
+        # the forward reads (word table, input encoders, TextBert, the heads) on the step's stream, the MMT's 42 M parameters on a stream of their own
+        # underneath TextBert's forward (a chain of 30 small kernels that leaves the GPU idle).  Same arithmetic in the same order (update k is complete
+        # before forward k + 1 reads a weight); between two steps the update is PENDING: flush_update() applies it (state_dict / checkpoints / an
+        # eval-mode forward of the model call it).  SAM_PIPELINE_UPDATE=0 or pipeline_update=False: the update closes its own step.
+        # Measured (round 4, c3 B=64): NOT a win -- any kernel running beside TextBert's chain slows the chain by 1.3-1.6x (385 -> 510-610 us even with the
+        # background piece held to 32-128 blocks), which eats what the overlap saves (step 6.22 -> 6.33 ms).  Kept as an option, default OFF.
+        self.pipeline_update = (os.environ.get("SAM_PIPELINE_UPDATE", "0") == "1") if pipeline_update is None else bool(pipeline_update)
+        self._pending = False
+        self._gate, self._gate_mirror, self._upd_stream = None, 0, None
+        import weakref
+        me = weakref.ref(self)
+
+        def _flush_before_eval(module, args):
+            t = me()
+            if t is not None and t._pending and not module.training and not torch.cuda.is_current_stream_capturing():
+                t.flush_update()
+        if hasattr(model, "register_forward_pre_hook"):
+            self._eval_hook = model.register_forward_pre_hook(_flush_before_eval)
         self.measure_comm, self._comm_events = False, []
         dropout_clock.manual_seed((int(seed) ^ (rank << 32)) & 0xFFFFFFFFFFFFFFFF)       # data-parallel replicas draw different masks
 
@@ -261,15 +281,23 @@ class Trainer:
         except Exception:
             return False
 
-    def _eager_step(self, batch_dict, sched_dev=None):
+    def _eager_step(self, batch_dict, sched_dev=None, pipelined=False):
         """everything one step enqueues.  sched_dev: device tensor [lr per group, 1 - beta1^t, 1 - beta2^t]; given, the optimizer kernel reads the
-        schedule from it (graph capture: by-value arguments would freeze at their capture-time values)"""
+        schedule from it (graph capture: by-value arguments would freeze at their capture-time values).  pipelined (capture only): the step OPENS
+        with the previous step's update (gated, _issue_pending_update) and leaves its own to the next replay."""
         model, flat = self.model, self.flat
+        if not pipelined:
+            self.flush_update()                                  # (an eager step between replays: the pending update first)
         if not model.training:
             model.train()                                        # (recursing over ~160 modules costs 0.6 ms of host time: only when needed)
         for layer in self._fresh_layers:
             layer._sam_grad_fresh = True                         # EncoderLayerFn.backward overwrites these gradients: they are not zeroed
-        flat.zero_grad(self._grad_keep_ranges())
+        if pipelined:
+            self._issue_pending_update(batch_dict)               # ... which also clears every gradient it has used: no zero-fill
+            # fresh dropout masks for this step (the counter / schedule half of sam_step_advance runs at the END of the step, into the real state)
+            ops.step_advance(self._rng_state, self.GRAPH_OFFSET_STRIDE, self._scratch_step, self.group_lr, self._scratch_sched, betas=self.betas, **self.schedule)
+        else:
+            flat.zero_grad(self._grad_keep_ranges())
         if self.reducer is not None:
             self.reducer.begin_step()
         parallel.active_reducer = self.reducer
@@ -310,6 +338,7 @@ class Trainer:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
         DeferredWgrads.flush()                                  # (normally empty: TextBert's embedding block flushed it in its backward)
+        DeferredWgrads.join()                                   # the MMT's last weight-gradient group ran on a stream of its own
         parallel.active_reducer = None
         if defer_ln:
             self._ln_flush()
@@ -323,7 +352,11 @@ class Trainer:
                 e1.record()
                 self._comm_events.append((e0, e1))
         ops.sumsq(flat.grad, self.gnorm_sq, sparse=self.sparse)     # global norm AFTER the all-reduce, as the reference clips reduced grads
-        if sched_dev is None:
+        if pipelined:
+            # t = ++step counter and the learning rates / bias corrections of THIS step's update, for the Adam pieces at the head of the next replay
+            # (or flush_update); nothing reads the schedule between here and there
+            ops.step_advance(self._scratch_rng, 0, self._step_dev, self.group_lr, sched_dev, betas=self.betas, **self.schedule)
+        elif sched_dev is None:
             ops.adam_step(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self.current_lrs(),
                           self.global_step + 1, gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps, sparse=self.sparse)
             self.global_step += 1
@@ -331,6 +364,46 @@ class Trainer:
             ops.adam_step_dev(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, sched_dev,
                               gnorm_sq=self.gnorm_sq, max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps, sparse=self.sparse)
         return loss.detach()
+
+    # ---- the update of a captured step, applied at the head of the next one -----------------------------------
+    def _update_split(self):
+        """first element of the piece that may run underneath the head of the forward: the MMT's parameters when they close the buffer"""
+        try:
+            lo, hi = self.flat.range_of(self.model.mmt)
+        except (ValueError, AttributeError, IndexError):
+            return self.flat.numel
+        sp = self.sparse
+        if hi != self.flat.numel or lo % 4 or lo == 0 or (sp is not None and sp[0] < lo < sp[1]):
+            return self.flat.numel
+        return lo
+
+    def _adam_piece(self, lo, hi, gate, max_blocks=0):
+        flat = self.flat
+        ops.adam_step_range(flat.flat, flat.grad, self.exp_avg, self.exp_avg_sq, flat.bf16, flat.segment_ends, self._sched_dev, lo, hi, gnorm_sq=self.gnorm_sq,
+                            max_norm=self.max_grad_norm, betas=self.betas, eps=self.eps, sparse=self.sparse, zero_grad=True, gate=gate, max_blocks=max_blocks)
+
+    def _issue_pending_update(self, batch_dict):
+        split, n = self._update_split(), self.flat.numel
+        self._adam_piece(0, split, self._gate)
+        if split < n:
+            main = torch.cuda.current_stream()
+            if self._upd_stream is None:
+                self._upd_stream = torch.cuda.Stream()
+            self._upd_stream.wait_stream(main)                   # after the first piece: that one has the whole memory system while the forward waits for it
+            with torch.cuda.stream(self._upd_stream):
+                self._adam_piece(split, n, self._gate, max_blocks=int(os.environ.get("SAM_UPDATE_BG_BLOCKS", "512")))     # (2 blocks per CU)
+            ev = torch.cuda.Event()
+            ev.record(self._upd_stream)
+            batch_dict["_sam_upd_event"] = ev                    # MMT.forward waits for it before it reads its first MMT parameter
+
+    def flush_update(self):
+        """apply the update a captured step left pending (no-op otherwise): after it the parameters, their bf16 shadows and the optimizer state are those
+        of `global_step` completed steps"""
+        if not self._pending:
+            return
+        self._adam_piece(0, self.flat.numel, None)
+        self._pending = False
+        self._bump_shadow_epoch()
 
     # ---- the step as ONE hipGraph ---------------------------------------------------------------------------
     # ~280 launches per step cost the host 4.7 ms (Python modules, autograd nodes, dispatcher) however they are issued; the step's shapes are
@@ -391,7 +464,15 @@ class Trainer:
         if self.global_step != self._dev_step_mirror:
             self._step_dev.fill_(self.global_step)
             self._dev_step_mirror = self.global_step
+        if self._pipelined_graph:
+            want = 1 if self._pending else 0
+            if want != self._gate_mirror:                        # (steady state: the gate stays 1 and nothing is enqueued here)
+                self._gate.fill_(want)
+                self._gate_mirror = want
+            if not self._pending:                                # a replay whose head update is gated off clears no gradient either
+                self.flat.zero_grad(self._grad_keep_ranges())
         self._graph.replay()
+        self._pending = self._pipelined_graph
         self.global_step += 1
         self._dev_step_mirror += 1
         return self._static_loss.clone()                         # (the static tensor is overwritten by the next replay: callers may keep what they get)
@@ -422,6 +503,14 @@ class Trainer:
         self._step_dev = torch.full((1,), self.global_step, dtype=torch.int64, device=dev)
         self._dev_step_mirror = self.global_step
         self._rng_state = torch.tensor([dropout_clock.seed & 0x7FFFFFFFFFFFFFFF, dropout_clock.offset + self.GRAPH_OFFSET_STRIDE], dtype=torch.int64, device=dev)
+        self._pipelined_graph = self.pipeline_update
+        if self._pipelined_graph:
+            self.flush_update()
+            self._gate = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._gate_mirror = 0
+            self._scratch_step = torch.zeros(1, dtype=torch.int64, device=dev)           # the rng half of sam_step_advance counts / schedules into these
+            self._scratch_sched = torch.zeros(n + 2, dtype=torch.float32, device=dev)
+            self._scratch_rng = torch.zeros(2, dtype=torch.int64, device=dev)            # ... and the schedule half advances this
         saved_offset, dropout_clock.offset = dropout_clock.offset, 0          # by-value offsets inside the graph: 1, 2, 3, ... per site
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
@@ -432,10 +521,13 @@ class Trainer:
         gc.disable()
         try:
             with torch.cuda.graph(g, stream=self._cap_stream):
-                # first node: fresh dropout masks, the step counter, this step's learning rates and bias corrections -- all on the device
-                ops.step_advance(self._rng_state, self.GRAPH_OFFSET_STRIDE, self._step_dev, self.group_lr, self._sched_dev, betas=self.betas, **self.schedule)
                 bd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in static_bd.items()}
-                loss = self._eager_step(bd, sched_dev=self._sched_dev)
+                if self._pipelined_graph:
+                    loss = self._eager_step(bd, sched_dev=self._sched_dev, pipelined=True)
+                else:
+                    # first node: fresh dropout masks, the step counter, this step's learning rates and bias corrections -- all on the device
+                    ops.step_advance(self._rng_state, self.GRAPH_OFFSET_STRIDE, self._step_dev, self.group_lr, self._sched_dev, betas=self.betas, **self.schedule)
+                    loss = self._eager_step(bd, sched_dev=self._sched_dev)
                 self._static_loss = loss
         finally:
             if gc_was_enabled:
@@ -476,6 +568,7 @@ class Trainer:
     def state_dict(self, current_val_score=None, epoch_id=None):
         """the dict train.py:177-187 hands to torch.save: model_state_dict, optimizer_state_dict (torch.optim.Adam layout),
         warmup_scheduler_state_dict (LambdaLR layout), global_step, current_val_score, epoch_id"""
+        self.flush_update()
         opt, sched = self._torch_optimizer(with_state=self.global_step > 0)
         return {"model_state_dict": {k: v.detach().clone().contiguous() for k, v in self.model.state_dict().items()},
                 "optimizer_state_dict": opt.state_dict(),
@@ -489,6 +582,7 @@ class Trainer:
 
     def load_model_state_dict(self, sd):
         """accepts an optional `module.` prefix (DataParallel checkpoints, evaluator.py:182-186)"""
+        self.flush_update()
         sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}
         missing = self.model.load_state_dict(sd, strict=True)
         self.flat.refresh_shadows()

@@ -186,6 +186,7 @@ for mode in ("dp_graph", "dp_eager", "plain_graph"):
         assert tr._graph is not None, "the step was not captured"
     if mode == "dp_graph":
         assert tr.reducer.late_buckets == 0 and all(tr.reducer.done)       # (state of the capture pass: every bucket left at a finality mark)
+    tr.flush_update()                                                      # (captured steps leave their update pending)
     res.append((losses, tr.flat.flat.clone()))
 torch.cuda.synchronize()
 (lg, pg), (le, pe), (lp, pp) = res

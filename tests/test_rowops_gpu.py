@@ -209,6 +209,47 @@ def test_row_sparse_region_is_bit_identical_to_the_dense_pass(route, monkeypatch
     assert never.sum() > 100 and torch.equal(state["sparse"][0][lo:hi].view(rows, d)[never], p0[lo:hi].view(rows, d)[never])
 
 
+def test_adam_in_gated_pieces_is_bit_identical_to_one_launch():
+    """sam_adam_step_range: the update applied as two pieces (the row-sparse table inside the first) gives, bit for bit, the parameters / moments / bf16
+    shadows of one sam_adam_step_dev launch; zero_grad clears exactly the gradient it has used; a closed gate (device word 0) leaves everything alone"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(8)
+    rows, d, head, mid, tail = 64, 768, 4096, 5000 * 4, 7001 * 4
+    lo, hi = head, head + rows * d
+    n = hi + mid + tail
+    split = hi + mid
+    p0, m0, v0 = torch.randn(n, generator=g), torch.randn(n, generator=g) * 0.01, torch.rand(n, generator=g) * 1e-4
+    grad0 = torch.randn(n, generator=g) * 0.05
+    touched = (torch.rand(rows, generator=g) > 0.5).to(torch.uint8)
+    grad0[lo:hi].view(rows, d)[touched == 0] = 0
+    m0[lo:hi].view(rows, d)[touched == 0] = 0
+    v0[lo:hi].view(rows, d)[touched == 0] = 0
+    sched = torch.tensor([1e-3, 3e-4, 1 - 0.9 ** 3, 1 - 0.999 ** 3], dtype=torch.float32).cuda()
+    nsq = (grad0.double() ** 2).sum().float().reshape(1).cuda()
+    seg = [split, n]
+    res = {}
+    for mode in ("one", "pieces", "closed"):
+        p, m, v, gr = p0.clone().cuda(), m0.clone().cuda(), v0.clone().cuda(), grad0.clone().cuda()
+        pb = p0.to(torch.bfloat16).cuda()
+        sp = (lo, hi, d, touched.cuda())
+        if mode == "one":
+            ops.adam_step_dev(p, gr, m, v, pb, seg, sched, gnorm_sq=nsq, max_norm=0.25, sparse=sp)
+        else:
+            gate = torch.tensor([0 if mode == "closed" else 1], dtype=torch.int32).cuda()
+            ops.adam_step_range(p, gr, m, v, pb, seg, sched, 0, split, gnorm_sq=nsq, max_norm=0.25, sparse=sp, zero_grad=True, gate=gate)
+            if mode == "pieces":
+                assert (gr[:split] == 0).all() and torch.equal(gr[split:].cpu(), grad0[split:])         # only the piece's own gradient is cleared
+            ops.adam_step_range(p, gr, m, v, pb, seg, sched, split, n, gnorm_sq=nsq, max_norm=0.25, sparse=sp, zero_grad=True, gate=gate)
+        res[mode] = tuple(t.cpu() for t in (p, m, v, pb, gr))
+    for a, b in zip(res["one"][:4], res["pieces"][:4]):
+        assert torch.equal(a, b)
+    assert (res["pieces"][4] == 0).all()
+    for a, b in zip(res["closed"], (p0, m0, v0, p0.to(torch.bfloat16), grad0)):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):                      # a piece may not cut the row-sparse region
+        ops.adam_step_range(p, gr, m, v, pb, seg, sched, 0, lo + d, sparse=(lo, hi, d, touched.cuda()))
+
+
 def test_sorted_embedding_backward_is_deterministic_and_equals_index_add():
     """sam_embedding_bwd_sorted (data-parallel row-sparse exchange): one writer per table row, duplicates summed in list order"""
     from sam_textvqa_amd import ops

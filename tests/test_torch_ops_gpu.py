@@ -145,6 +145,9 @@ def test_training_step_captured_as_a_hipgraph():
         tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=use_graph, schedule=dict(warmup_iters=4))      # LR changes every step
         losses = [tr.step(clone_batch(batch)).item() for _ in range(7)]
         assert (tr._graph is not None) == use_graph and tr.global_step == 7
+        assert tr._pending == use_graph                  # the captured step leaves its update to the head of the next replay ...
+        tr.flush_update()                                 # ... or to whoever needs the parameters first
+        assert not tr._pending
         runs.append((losses, tr.flat.flat.clone(), tr.exp_avg_sq.clone()))
     (l0, p0, v0), (l1, p1, v1) = runs
     assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)      # (two scatter kernels use fp32 atomics: not bit-reproducible)
@@ -163,13 +166,58 @@ def test_training_step_captured_as_a_hipgraph():
     tr = Trainer(model, base_lr=2e-4, seed=3, use_graph=True)
     before = tr.flat.flat.clone()
     tr.step(clone_batch(batch)); tr.step(clone_batch(batch))
+    tr.flush_update()
     frozen = tr.flat.flat.clone()
     a = tr.step(clone_batch(batch)).item()
+    tr.flush_update()
     tr.flat.flat.copy_(frozen); tr.flat.refresh_shadows()          # same weights, same batch, next replay: only the masks differ
     b = tr.step(clone_batch(batch)).item()
     assert tr._graph is not None and a != b and abs(a - b) < 0.2 * abs(a), (a, b)
     ls = [tr.step(clone_batch(batch)).item() for _ in range(30)]
     assert ls[-1] < 0.8 * ls[0] and not torch.equal(before, tr.flat.flat)
+
+
+def test_update_at_the_head_of_the_next_replay_is_the_same_training_run():
+    """Trainer(pipeline_update=True): clip + Adam of step k open replay k + 1 (two gated pieces, the MMT's under TextBert's forward) instead of closing
+    replay k.  Dropout off: losses, parameters, moments and bf16 shadows after flush_update() equal the closing-update run's (identical kernels on
+    identical operands; the two scatter kernels' fp32 atomics are the only noise); state_dict() and an eval-mode forward flush by themselves; an eager
+    step of another shape in between and the replay after it (gate closed) keep the trajectory."""
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch
+    from sam_textvqa_amd.trainer import Trainer
+    from tests.test_model_gpu import _small_full_model
+    batch = make_batch(4, vocab=300, device="cuda", seed=21)
+    batch["question_indices"] = batch["question_indices"] % 500
+    small = make_batch(2, vocab=300, device="cuda", seed=5)
+    small["question_indices"] = small["question_indices"] % 500
+    runs = []
+    for pipe in (False, True):
+        model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
+        tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=True, schedule=dict(warmup_iters=4), pipeline_update=pipe)
+        losses = [tr.step(clone_batch(batch)).item() for _ in range(5)]
+        assert tr._graph is not None and tr._pending == pipe
+        if pipe:
+            assert tr._update_split() < tr.flat.numel                  # the MMT's parameters close the buffer: two pieces
+            stale = tr.flat.flat.clone()
+            sd = tr.state_dict()                                        # flushes
+            assert not tr._pending and not torch.equal(stale, tr.flat.flat)
+            assert sd["global_step"] == 5
+        losses.append(tr.step(clone_batch(small)).item())               # another shape: eager, between two replays
+        losses += [tr.step(clone_batch(batch)).item() for _ in range(3)]        # the first of these replays runs with its gate closed
+        if pipe:
+            assert tr._pending
+            model.eval()
+            with torch.no_grad():
+                model(clone_batch(batch))                               # an eval-mode forward applies the pending update first
+            assert not tr._pending
+            model.train()
+        assert tr.global_step == 9
+        runs.append((losses, tr.flat.flat.clone(), tr.exp_avg.clone(), tr.exp_avg_sq.clone(), tr.flat.bf16.clone(), tr.flat.grad.clone()))
+    (l0, p0, m0, v0, b0, g0), (l1, p1, m1, v1, b1, g1) = runs
+    assert all(abs(a - b) <= 2e-3 * abs(a) for a, b in zip(l0, l1)), (l0, l1)
+    assert (p0 - p1).abs().max().item() < 5e-3 and (m0 - m1).abs().max().item() < 1e-3 and (v0 - v1).abs().max().item() < 1e-4
+    assert (b0.float() - b1.float()).abs().max().item() < 1e-2
+    assert torch.equal(b1.float(), p1.to(torch.bfloat16).float())       # the shadows are the rounded masters after the flush
+    assert (g1 == 0).all()                                              # ... and the applied update has cleared its gradients
 
 
 def test_survey_8b_ops_equal_the_cabi_route():

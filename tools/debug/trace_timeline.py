@@ -6,7 +6,7 @@ def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     return n.split('(')[0][:70]
 # steps delimited by adam_kernel
-adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+adam = [i for i, r in enumerate(rows) if "sumsq_final" in r["Kernel_Name"]]
 lo, hi = adam[-2] + 1, adam[-1] + 1
 seg = rows[lo:hi]
 t0 = int(seg[0]['Start_Timestamp'])
