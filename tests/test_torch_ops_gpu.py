@@ -145,8 +145,8 @@ def test_training_step_captured_as_a_hipgraph():
         tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=use_graph, schedule=dict(warmup_iters=4))      # LR changes every step
         losses = [tr.step(clone_batch(batch)).item() for _ in range(7)]
         assert (tr._graph is not None) == use_graph and tr.global_step == 7
-        assert tr._pending == use_graph                  # the captured step leaves its update to the head of the next replay ...
-        tr.flush_update()                                 # ... or to whoever needs the parameters first
+        assert tr._pending == (use_graph and tr.pipeline_update)      # (pipeline_update: the captured step leaves its update to the next replay's head ...
+        tr.flush_update()                                              # ... or to whoever needs the parameters first; a no-op otherwise)
         assert not tr._pending
         runs.append((losses, tr.flat.flat.clone(), tr.exp_avg_sq.clone()))
     (l0, p0, v0), (l1, p1, v1) = runs
