@@ -77,6 +77,12 @@ int sam_attn_fwd_rows(const void* qkv, const uint32_t* allow, int64_t allow_stri
  * the decoder rows only.  Same arithmetic per row as sam_attn_fwd (the results are bit-identical to a full pass over the same values). */
 int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
                      int H, int head_dim, float scale, void* out_dec, void* stream);
+/* the same step for beam search (sam/beam_search.py:31-82 repeats every sample beam_size times; sam/sa_m4c.py:304-314 then runs full forwards over the
+ * copies): the `group` beams of a sample have the SAME text / object / OCR rows in every layer, so qkv_enc [B/group * N, 3*H*64] and the allow words
+ * (sample stride allow_stride_b) are kept ONCE per sample and decoder sample b reads those of sample b / group; qkv_dec / out_dec have B = samples x group
+ * decoder blocks.  group = 1 is sam_attn_fwd_dec. */
+int sam_attn_fwd_dec_shared(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int group,
+                            int N, int n_dec, int H, int head_dim, float scale, void* out_dec, void* stream);
 /* training forward: sam_attn_fwd plus out_lo bf16 [B*N, H*64] = bf16(out_exact - bf16(out_exact)), the rounding residual of the output.  The one-pass
  * backward takes delta = rowsum(dO * O) from out + out_lo (exact to 2^-17; the bf16 output alone costs 3e-3 of max in dQ / dK), which is what lets it
  * compute every score once instead of running a row pass for delta first.  Replaces sam/sa_m4c.py:563-598 as sam_attn_fwd does. */
@@ -310,7 +316,8 @@ int sam_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
  *   token = idx % (V+No); cum[new] = cum[src] + value (the value already holds cum[src]: counted twice, as upstream).
  *   ctl = NULL: the step index is `t`.  ctl = int32[4] in device memory {t, finished, 0, 0} (zero-filled before the first step): the step index is
  *   ctl[0], advanced by the launch itself, and once every beam is complete (or the steps ran out) ctl[1] is set and later launches leave the state
- *   untouched -- what lets ONE captured decoding step be replayed S - 1 times with the reference's early exit. */
+ *   untouched (prev_pos, when given, then receives the identity) -- what lets captured decoding steps be replayed S - 1 times with the reference's
+ *   early exit. */
 int sam_greedy_pick(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int R, int S, int V, int No, int64_t* prev_inds,
                     void* stream);
 int sam_beam_step(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,

@@ -159,7 +159,8 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
   const int tid = threadIdx.x, bh = blockIdx.x, b = bh / a.H, h = bh % a.H;
   const int N = a.N, Dm = a.H * HD;
   const int64_t ld = 3 * (int64_t)Dm;
-  const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
+  const int be = DEC ? b / a.kv_group : b;            // the sample whose encoder rows / allow words this block reads (beams share them)
+  const bf16_t* qbase = a.qkv + (int64_t)be * N * ld + h * HD;
   const bf16_t* dbase = DEC ? a.qkv_dec + (int64_t)b * (N - a.n_enc) * ld + h * HD : nullptr;
   const int lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
 
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(NT, fwd_waves_per_eu(NKT, NT)) void attn_fwd_kernel
     const bf16_t* qrow = (DEC && q >= a.n_enc) ? dbase + (int64_t)(q - a.n_enc) * ld : qbase + (int64_t)q * ld;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) qf_n[ks] = *reinterpret_cast<const bf16x8*>(qrow + 32 * ks + 8 * g);
-    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)q * a.NW;
+    const uint32_t* ap = a.allow + be * a.allow_sb + h * a.allow_sh + (int64_t)q * a.NW;
 #pragma unroll
     for (int w = 0; w < NKT / 2; ++w) naw_n[w] = ap[w];
   };
@@ -700,16 +701,21 @@ int launch_fwd_any(const AttnArgs& a, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
-                                int H, int head_dim, float scale, void* out_dec, void* stream) {
+extern "C" int sam_attn_fwd_dec_shared(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int group,
+                                       int N, int n_dec, int H, int head_dim, float scale, void* out_dec, void* stream) {
   AttnArgs a = {};
   int rc = fill_common(a, B, N, H, head_dim, scale, 0.f);
   if (rc) return rc;
   SAM_REQUIRE(qkv_enc && qkv_dec && allow && out_dec, "sam_attn_fwd_dec: null pointer");
   SAM_REQUIRE(n_dec > 0 && n_dec < N, "sam_attn_fwd_dec: n_dec=%d outside (0,%d)", n_dec, N);
-  a.qkv = (const bf16_t*)qkv_enc; a.qkv_dec = (const bf16_t*)qkv_dec; a.out_dec = (bf16_t*)out_dec; a.n_enc = N - n_dec;
+  SAM_REQUIRE(group >= 1 && B % group == 0, "sam_attn_fwd_dec_shared: B=%d is not a whole number of groups of %d", B, group);
+  a.qkv = (const bf16_t*)qkv_enc; a.qkv_dec = (const bf16_t*)qkv_dec; a.out_dec = (bf16_t*)out_dec; a.n_enc = N - n_dec; a.kv_group = group;
   a.allow = allow; a.allow_sb = allow_stride_b; a.allow_sh = allow_stride_h; a.q_begin = N - n_dec;
   return launch_fwd_any<true>(a, (hipStream_t)stream);
+}
+extern "C" int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int n_dec,
+                                int H, int head_dim, float scale, void* out_dec, void* stream) {
+  return sam_attn_fwd_dec_shared(qkv_enc, qkv_dec, allow, allow_stride_b, allow_stride_h, B, 1, N, n_dec, H, head_dim, scale, out_dec, stream);
 }
 
 extern "C" int sam_attn_words_per_row(int N) {

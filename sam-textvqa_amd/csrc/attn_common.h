@@ -117,6 +117,7 @@ struct AttnArgs {
   const bf16_t* qkv_dec;
   bf16_t* out_dec;
   int n_enc;
+  int kv_group;      // decoding: consecutive groups of kv_group decoder samples (the beams of one sample) share ONE sample's encoder rows and allow words (>= 1)
   float scale, scale_log2, p_drop, inv_keep;
   float ds_c1;            // fused bwd: inv_keep * scale * 2^(-36 - ds_sh), see attention_bwd_fused.hip
   int ds_sh;

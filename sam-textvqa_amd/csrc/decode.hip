@@ -69,7 +69,10 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const float* __restrict__
   __shared__ int64_t s_seq[KMAX * 64];
   const int b = blockIdx.x, tid = threadIdx.x, Vt = V + No;
   const int t = ctl ? ctl[0] : t_by_value;
-  if (ctl && ctl[1]) return;                       // the search is over: state untouched
+  if (ctl && ctl[1]) {                             // the search is over: state untouched, every beam its own source
+    if (prev_pos && tid < K) prev_pos[b * K + tid] = b * K + tid;
+    return;
+  }
   if (tid < K) { s_cum[tid] = cum[b * K + tid]; s_done[tid] = done[b * K + tid]; }
   for (int e = tid; e < K * S; e += NT) s_seq[e] = seqs[(int64_t)b * K * S + e];
   __syncthreads();

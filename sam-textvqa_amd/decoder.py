@@ -14,12 +14,21 @@ eager PyTorch in between.  Here:
   * greedy decoding goes one step further (sam_greedy_decode_steps, csrc/decode_steps.hip): step t only has ONE new row per sample -- decoder
     row t, whose token step t-1 picked and which never changes afterwards -- so steps 1..n_dec-1 run as a single persistent kernel whose phases
     (projection, attention over the cached keys / values, output projection + LayerNorm, FFN + LayerNorm, classifier, pointer scores, argmax,
-    next embedding) are separated by grid barriers instead of ~56 launches per step.  The per-kernel step stays for beam search (beams are
-    re-gathered between steps) and for model shapes the fused kernel is not built for (SAM_DECODE_FUSED=0 forces it).
-Beam search keeps the reference's structure -- every sample repeated beam_size times, candidates ranked over the flattened [beam, vocab] axis,
-surviving beams re-gathered -- and its exact arithmetic, including the quirks listed in oracle/beam_search.py (integer `indices / vocab_size`,
-cumulative scores that count the source beam twice, completed beams forced onto EOS); the re-gathering of the batch's feature tensors by
-`prev_position` (beam_search.py:131-137) permutes identical copies inside one sample's group and is therefore not executed."""
+    next embedding) are separated by grid barriers instead of ~56 launches per step.  The per-kernel step stays for model shapes the fused
+    kernel is not built for (SAM_DECODE_FUSED=0 forces it).
+Beam search keeps the reference's structure -- beam_size hypotheses per sample, candidates ranked over the flattened [beam, vocab] axis, surviving
+beams re-gathered -- and its exact arithmetic, including the quirks listed in oracle/beam_search.py (integer `indices / vocab_size`, cumulative
+scores that count the source beam twice, completed beams forced onto EOS).  What it does not repeat is the work the reference's layout makes
+redundant (round 4: 21.8 -> 11.8 ms per batch of 64 at beam 5):
+  * the beam_size copies of a sample (beam_search.py:31-82) have identical text / object / OCR rows in every layer and every step, so the batch is
+    NOT expanded: the first pass runs once per sample and the steps' decoder rows read the one cached copy (sam_attn_fwd_dec_shared); the
+    re-gathering of the feature tensors by `prev_position` (beam_search.py:131-137) permutes identical copies and is not executed
+    (SAM_BEAM_SHARED=0: the expanded batch);
+  * under the causal part of the mask the decoder rows before position t of a surviving beam are those of the beam it continues: their keys /
+    values are re-gathered by source row and only row t is computed per step (DecodeSession._step_inc; scores and hidden states are collected per
+    position and put into the order of the returned beams through an ancestry table); SAM_BEAM_INCREMENTAL=0 recomputes all decoder rows of
+    all beams every step, as the reference does.  One difference in what nobody reads: when the search ends before the last position, the scores
+    of the positions AFTER the step that ended it come from the continued decoding, not from the zero tokens the reference's last forward saw."""
 import math
 import os
 
@@ -141,8 +150,14 @@ def _log_fallback(why):
 class DecodeSession:
     """static buffers + the two captured graphs for one (model, input shapes, beam size)"""
 
-    def __init__(self, model, batch_dict, beam=0, eos_idx=None):
+    def __init__(self, model, batch_dict, beam=0, eos_idx=None, shared=False):
+        """shared (beam search only): batch_dict holds the UNEXPANDED batch.  The beams of a sample have identical text / object / OCR rows in every
+        layer and in every step (prefix-LM mask), so the first pass runs once per SAMPLE and the steps' decoder rows -- beam x more of them -- read
+        the one cached copy (sam_attn_fwd_dec_shared); at t = 0 only a sample's first beam is live (beam_search.py:98-105) and all of its beams hold
+        the same scores.  Same arithmetic per row as the expanded batch, a fifth of the first pass and of the cache at beam 5."""
         self.model, self.beam = model, int(beam)
+        self.group = int(beam) if (shared and beam) else 1
+        self.incremental = bool(beam) and os.environ.get("SAM_BEAM_INCREMENTAL", "1") != "0"
         self.eos = eos_idx
         self.items = _flatten(batch_dict)
         self.sig = signature(batch_dict, beam)
@@ -154,7 +169,8 @@ class DecodeSession:
                 self.bd[k] = t
             else:
                 self.bd.setdefault(k, {})[kk] = t
-        self.rows, self.steps = self.bd["train_prev_inds"].shape
+        self.rows_in, self.steps = self.bd["train_prev_inds"].shape
+        self.rows = self.rows_in * self.group
         self.graph_first = self.graph_step = None
         self.pool = None
         self.fused = None          # decided after the first pass: (layers, desc, workspace) of sam_greedy_decode_steps, or False
@@ -170,8 +186,16 @@ class DecodeSession:
         m._forward_ocr_encoding(bd)
         m._forward_text_bert(bd)
         self.enc = (bd["text_bert_emb"], bd["obj_mmt_in"], bd["ocr_mmt_in"])
-        r, s = self.rows, self.steps
-        self.prev = self.bd["train_prev_inds"]
+        r, s, k = self.rows, self.steps, self.group
+        r0 = self.rows_in
+        prev_in = self.bd["train_prev_inds"]
+        if k == 1:
+            self.prev = prev_in
+        else:
+            if getattr(self, "_prev_k", None) is None:
+                self._prev_k = torch.empty((r, s), dtype=prev_in.dtype, device=prev_in.device)     # (a buffer of the session: both graphs work on it in place)
+            self.prev = self._prev_k
+            self.prev.copy_(prev_in.repeat_interleave(k, dim=0))
         if self.beam == 0:                                   # sa_m4c.py:287-291: BOS, then zeros (beam search starts from the caller's tensor)
             self.prev.zero_()
             self.prev[:, 0] = m.bos_idx
@@ -179,6 +203,7 @@ class DecodeSession:
             self.cum = torch.zeros(r, dtype=torch.float32, device=self.prev.device)
             self.done = torch.zeros(r, dtype=torch.uint8, device=self.prev.device)
             self.ctl = torch.zeros(4, dtype=torch.int32, device=self.prev.device)
+            self.prev_pos = torch.arange(r, dtype=torch.int64, device=self.prev.device)
         # PrevPredEmbeddings: the step-invariant halves (sa_m4c.py:921-927)
         pp = mmt.prev_pred_embeddings
         ans_w = m.classifier.weight
@@ -187,40 +212,68 @@ class DecodeSession:
         self.ans_ln = ops.layernorm_fwd(ans_x, pp.ans_layer_norm.weight, pp.ans_layer_norm.bias, pp.ans_layer_norm.variance_epsilon)[0]
         ocr_in = bd["ocr_mmt_in"]
         self.n_ocr = ocr_in.shape[1]
-        ocr_x = ocr_in.reshape(r * self.n_ocr, -1)
-        self.ocr_ln = ops.layernorm_fwd(ocr_x if ocr_x.is_contiguous() else ocr_x.contiguous(), pp.ocr_layer_norm.weight, pp.ocr_layer_norm.bias,
-                                        pp.ocr_layer_norm.variance_epsilon)[0]
-        x_dec = self._dec_embed()
+        ocr_x = ocr_in.reshape(r0 * self.n_ocr, -1)
+        ocr_ln0 = ops.layernorm_fwd(ocr_x if ocr_x.is_contiguous() else ocr_x.contiguous(), pp.ocr_layer_norm.weight, pp.ocr_layer_norm.bias,
+                                    pp.ocr_layer_norm.variance_epsilon)[0]
+        # (shared beams: the small per-sample operands of the steps -- OCR rows of PrevPredEmbeddings, pointer keys, OCR mask -- are repeated per beam
+        # once per batch, 25 MB each; the layers' keys / values, 45 MB per layer and sample group, are not)
+        self.ocr_ln = ocr_ln0 if k == 1 else ocr_ln0.view(r0, -1).repeat_interleave(k, dim=0).view(r * self.n_ocr, -1)
+        x_dec = self._dec_embed(prev_in, ocr_ln0)
         d = x_dec.shape[1]
-        x = torch.cat([bd["text_bert_emb"].to(BF16), bd["obj_mmt_in"].to(BF16), bd["ocr_mmt_in"].to(BF16), x_dec.view(r, s, d)], dim=1)
+        x = torch.cat([bd["text_bert_emb"].to(BF16), bd["obj_mmt_in"].to(BF16), bd["ocr_mmt_in"].to(BF16), x_dec.view(r0, s, d)], dim=1)
         self.n = x.shape[1]
         n_txt, n_obj = bd["question_mask"].size(-1), bd["pad_obj_mask"].size(-1)
         from .modules import AllowBits
         allow = AllowBits(ops.mask_bits_prefix_lm(bd["_sam_masks_u8"][0], s))
         self.plan = mmt.encoder._layer_plan(allow, bd, None)
-        self.ocr_mask = bd["_sam_masks_u8"][2]
-        seq2d, caches = mmt.encoder.infer_full(x.reshape(r * self.n, d).contiguous(), allow, bd, r)
+        ocr_mask0 = bd["_sam_masks_u8"][2]
+        seq2d, caches = mmt.encoder.infer_full(x.reshape(r0 * self.n, d).contiguous(), allow, bd, r0)
         self.caches = caches
-        self.seq = seq2d.view(r, self.n, d)
+        self.seq = seq2d.view(r0, self.n, d)
         ocr0 = n_txt + n_obj
         self.ocr0 = ocr0
         ocr_rows = self.seq[:, ocr0: ocr0 + self.n_ocr].contiguous()
         pk = m.ocr_ptr_net.key                                                  # pointer-network keys: OCR rows are step-invariant
         wv, _, bv, _, _, _ = _padded_views(pk.weight, pk.bias)
-        self.ptr_k = ops.gemm(ocr_rows.view(r * self.n_ocr, d), wv, epilogue=capi.EPI_BIAS, bias=bv).view(r, self.n_ocr, -1)
-        y_dec = self.seq[:, self.n - s:].reshape(r * s, d)
-        self.out_first = self._head_and_pick(y_dec)
+        ptr_k0 = ops.gemm(ocr_rows.view(r0 * self.n_ocr, d), wv, epilogue=capi.EPI_BIAS, bias=bv).view(r0, self.n_ocr, -1)
+        y_dec = self.seq[:, self.n - s:].reshape(r0 * s, d)
+        if self.incremental:
+            # beam search, one NEW decoder row per step (_step_inc): per layer the decoder rows' q|k|v of the first pass, one block per beam, in two
+            # buffers (re-gathered from one into the other by the surviving beams' source rows every step); scores / hidden states are collected
+            # position by position and put in the order of the final beams through `anc` at the end
+            d3 = caches[0][0].shape[1]
+            self.dec_qkv = []
+            for qkv_full, _, _ in caches:
+                blk = qkv_full.view(r0, self.n, d3)[:, self.n - s:]
+                blk = (blk if k == 1 else blk.repeat_interleave(k, dim=0)).reshape(r * s, d3).contiguous()
+                self.dec_qkv.append((blk, torch.empty_like(blk)))
+            self.ident = torch.arange(r, dtype=torch.int64, device=self.prev.device)
+            self.anc = self.ident.repeat(s, 1)
+            yd = self.seq[:, self.n - s:]
+            self.y_hist = (yd if k == 1 else yd.repeat_interleave(k, dim=0)).contiguous()
+        if k == 1:
+            self.ptr_k, self.ocr_mask = ptr_k0, ocr_mask0
+            self.out_first = self._head_and_pick(y_dec, 0 if self.incremental else None)
+        else:
+            fixed0, dyn0 = self._head(y_dec, ptr_k0, ocr_mask0, r0)
+            self.ptr_k, self.ocr_mask = ptr_k0.repeat_interleave(k, dim=0), ocr_mask0.repeat_interleave(k, dim=0)
+            fixed = fixed0.reshape(r0, -1).repeat_interleave(k, dim=0).view(r * s, -1)           # every beam of a sample: the sample's scores
+            dyn = dyn0.repeat_interleave(k, dim=0)
+            self.out_first = (fixed, dyn)
+            self._pick(fixed, dyn.view(r * s, -1), 0 if self.incremental else None)
         if self.fused is None or self.fused:
             self.fused = self._fused_plan()         # (rebuilt on every _first: the capture's allocations replace the eager round's)
 
-    def _dec_embed(self):
+    def _dec_embed(self, prev=None, ocr_ln=None):
         """PrevPredEmbeddings.forward for the current train_prev_inds, eval mode (sa_m4c.py:928-948) -> bf16 [R*S, D]"""
         pp = self.model.mmt.prev_pred_embeddings
-        r, s = self.rows, self.steps
-        is_ocr = self.prev.ge(self.n_ans).view(torch.uint8).reshape(-1)
+        prev = self.prev if prev is None else prev
+        ocr_ln = self.ocr_ln if ocr_ln is None else ocr_ln
+        r, s = prev.shape
+        is_ocr = prev.ge(self.n_ans).view(torch.uint8).reshape(-1)
         e = ops.embed_sum_fwd(pp.position_embeddings.weight.data, pp.token_type_embeddings.weight.data, r * s, s, type_ids=is_ocr)
         emb = ops.layernorm_fwd(e, pp.emb_layer_norm.weight, pp.emb_layer_norm.bias, pp.emb_layer_norm.variance_epsilon)[0]
-        return ops.gather2_add_fwd(self.ans_ln, self.ocr_ln, self.prev, self.n_ocr, emb, 0.0)
+        return ops.gather2_add_fwd(self.ans_ln, ocr_ln, prev, self.n_ocr, emb, 0.0)
 
     def _step(self):
         """one decoding step: the decoder rows through every layer against the cached encoder keys / values, then the token selection"""
@@ -231,7 +284,7 @@ class DecodeSession:
             att = layer.attention.self
             wqkv, bqkv, _, _ = _fused_qkv(att)
             qkv_dec = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
-            ctx = ops.attn_fwd_dec(qkv_full, qkv_dec, bits, r, self.n, s, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size))
+            ctx = ops.attn_fwd_dec(qkv_full, qkv_dec, bits, r, self.n, s, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), kv_group=self.group)
             x = _layer_tail(layer, ctx, x)
         self.y_dec = x
         self.out_step = self._head_and_pick(x)
@@ -324,10 +377,10 @@ class DecodeSession:
         self.out_step = self.out_first
         self.y_dec = None
 
-    def _head_and_pick(self, y_dec):
-        """classifier + pointer network on the decoder rows (sa_m4c.py:270-278), then the token selection in place on the decoder state"""
+    def _head(self, y_dec, ptr_k, ocr_mask, r, s=None):
+        """classifier + pointer network on the decoder rows (sa_m4c.py:270-278) -> (fixed f32 [r*S, V], dyn f32 [r, S, n_ocr])"""
         m = self.model
-        r, s = self.rows, self.steps
+        s = self.steps if s is None else s
         wv, _, bv, _, n_pad, _ = _padded_views(m.classifier.weight, m.classifier.bias)
         fixed = ops.gemm(y_dec, wv, epilogue=capi.EPI_BIAS, bias=bv, out_dtype=torch.float32)
         if n_pad != m.classifier.weight.shape[0]:
@@ -335,12 +388,53 @@ class DecodeSession:
         pq = m.ocr_ptr_net.query
         wq, _, bq, _, _, _ = _padded_views(pq.weight, pq.bias)
         q = ops.gemm(y_dec, wq, epilogue=capi.EPI_BIAS, bias=bq).view(r, s, -1)
-        dyn = ops.ptr_scores_fwd(q, self.ptr_k, self.ocr_mask, 1.0 / math.sqrt(m.ocr_ptr_net.query_key_size))
-        dyn2 = dyn.view(r * s, -1)
+        dyn = ops.ptr_scores_fwd(q, ptr_k, ocr_mask, 1.0 / math.sqrt(m.ocr_ptr_net.query_key_size))
+        return fixed, dyn
+
+    def _pick(self, fixed, dyn2, t=None):
+        """the token selection, in place on the decoder state.  t (incremental beam steps): the position just scored -- rows 0..t of `anc` follow the
+        surviving beams back to the rows that hold their scores, unless this step ended the search (the reference returns the scores of the beams as
+        they were BEFORE the last re-gathering, sa_m4c.py:304-314 / beam_search.py:149-158)"""
         if self.beam == 0:
             ops.greedy_pick(fixed, dyn2, self.prev)
-        else:
-            ops.beam_step(fixed, dyn2, r // self.beam, self.beam, self.prev, self.cum, self.done, self.eos, ctl=self.ctl)
+            return
+        ops.beam_step(fixed, dyn2, self.rows // self.beam, self.beam, self.prev, self.cum, self.done, self.eos, ctl=self.ctl, prev_pos=self.prev_pos)
+        if t is not None and t + 1 < self.steps:
+            pp = torch.where(self.ctl[1] != 0, self.ident, self.prev_pos)
+            self.anc[: t + 1] = self.anc[: t + 1].index_select(1, pp)
+
+    def _step_inc(self, t):
+        """decoding step t of a beam search, ONE new row per beam: under the causal part of the mask the decoder rows before position t of a beam are
+        those of the beam it continues, so their keys / values are re-gathered by source row (what sam/beam_search.py:131-137 does to the whole batch)
+        instead of being recomputed; row t goes through every layer against them and the cached encoder rows"""
+        from .modules import _layer_tail
+        r, s, k = self.rows, self.steps, self.group
+        src, dst = (0, 1) if t % 2 == 1 else (1, 0)          # (step 1 reads the first-pass buffers)
+        x_all = self._dec_embed()
+        d = x_all.shape[1]
+        x = x_all.view(r, s, d)[:, t]
+        for (layer, bits), (qkv_full, _, _), bufs in zip(self.plan, self.caches, self.dec_qkv):
+            att = layer.attention.self
+            wqkv, bqkv, _, _ = _fused_qkv(att)
+            cur, nxt = bufs[src], bufs[dst]
+            d3 = cur.shape[1]
+            torch.index_select(cur.view(r, s * d3), 0, self.prev_pos, out=nxt.view(r, s * d3))
+            ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv, out=nxt.view(r, s, d3)[:, t])
+            ctx = ops.attn_fwd_dec(qkv_full, nxt, bits, r, self.n, s, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), kv_group=k)
+            x = _layer_tail(layer, ctx.view(r, s, -1)[:, t], x)
+        self.y_hist[:, t] = x
+        fixed_t, dyn_t = self._head(x, self.ptr_k, self.ocr_mask, r, 1)
+        fixed, dyn = self.out_first
+        ld = fixed.stride(0)
+        torch.as_strided(fixed, (r, fixed.shape[1]), (s * ld, 1), fixed.storage_offset() + t * ld).copy_(fixed_t)
+        dyn[:, t] = dyn_t[:, 0]
+        self._pick(fixed, dyn.view(r * s, -1), t)
+        self.out_step = self.out_first
+        self.y_dec = None
+
+    def _head_and_pick(self, y_dec, t=None):
+        fixed, dyn = self._head(y_dec, self.ptr_k, self.ocr_mask, self.rows)
+        self._pick(fixed, dyn.view(self.rows * self.steps, -1), t)
         return fixed, dyn
 
     # ---- running it ------------------------------------------------------------------------------------------
@@ -366,14 +460,19 @@ class DecodeSession:
             if self.fused:
                 self._steps_fused()
             else:
-                for _ in range(self.steps - 1):
-                    self._step()
+                for t in range(1, self.steps):
+                    self._step_inc(t) if self.incremental else self._step()
                     last = self.out_step
         else:
             self.graph_first.replay()
             last = self.out_first
-            for _ in range(1 if self.fused else self.steps - 1):
-                self.graph_step.replay()
+            if self.incremental:
+                for g in self.graph_steps:
+                    g.replay()
+            else:
+                for _ in range(1 if self.fused else self.steps - 1):
+                    self.graph_step.replay()
+            if self.steps > 1:
                 last = self.out_step
         if self.fused:
             inject = os.environ.get("SAM_DECODE_INJECT_ERR")          # (test hook: pretend the kernel reported this code)
@@ -424,7 +523,10 @@ class DecodeSession:
         st.wait_stream(cur)
         with torch.cuda.stream(st):
             self._first()
-            if self.steps > 1:
+            if self.steps > 1 and self.incremental:
+                for t in range(1, self.steps):
+                    self._step_inc(t)
+            elif self.steps > 1:
                 if self.fused:
                     try:
                         self._steps_fused()
@@ -442,7 +544,14 @@ class DecodeSession:
             self._first()
         self.pool = g1.pool()
         g2 = torch.cuda.CUDAGraph()
-        if self.steps > 1:
+        self.graph_steps = []
+        if self.incremental:                     # one graph per position: its row offsets are by-value arguments
+            for t in range(1, self.steps):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool, stream=st):
+                    self._step_inc(t)
+                self.graph_steps.append(g)
+        elif self.steps > 1:
             with torch.cuda.graph(g2, pool=self.pool, stream=st):
                 self._steps_fused() if self.fused else self._step()
         self.graph_first, self.graph_step = g1, g2
@@ -450,7 +559,15 @@ class DecodeSession:
     def _results(self, batch_dict, last):
         fixed, dyn = last
         r, s = self.rows, self.steps
-        scores = torch.cat([fixed.view(r, s, -1), dyn], dim=-1)
+        if self.incremental and s > 1:
+            # position j of a returned beam was scored when its ancestor stood in row anc[j, beam]
+            rows, cols = self.anc.t(), torch.arange(s, device=self.anc.device)
+            ld = fixed.stride(0)
+            fixed3 = torch.as_strided(fixed, (r, s, fixed.shape[1]), (s * ld, ld, 1), fixed.storage_offset())
+            scores = torch.cat([fixed3[rows, cols], dyn[rows, cols]], dim=-1)
+            self.y_dec = self.y_hist[rows, cols].reshape(r * s, -1)
+        else:
+            scores = torch.cat([fixed.view(r, s, -1), dyn], dim=-1)
         batch_dict["scores"] = scores
         # the two blocks as views of the fresh concatenation, not of the session's static buffers (which the next batch overwrites in place: an evaluator
         # that collects per-batch outputs must not see them change).  text_bert_emb / obj_mmt_in / ocr_mmt_in below ARE the session's buffers: valid
@@ -458,12 +575,13 @@ class DecodeSession:
         n_fixed = fixed.view(r, s, -1).shape[-1]
         batch_dict["fixed_scores"], batch_dict["dynamic_ocr_scores"] = scores[..., :n_fixed], scores[..., n_fixed:]
         batch_dict["train_prev_inds"] = self.prev.clone()
-        batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"] = self.enc
-        seq = self.seq.clone()
+        k = self.group
+        batch_dict["text_bert_emb"], batch_dict["obj_mmt_in"], batch_dict["ocr_mmt_in"] = self.enc if k == 1 else tuple(t.repeat_interleave(k, dim=0) for t in self.enc)
+        seq = self.seq.clone() if k == 1 else self.seq.repeat_interleave(k, dim=0)
         if self.steps > 1 and self.y_dec is not None:
             seq[:, self.n - s:] = self.y_dec.view(r, s, -1)
         batch_dict["mmt_seq_output"] = seq
-        n_txt = batch_dict["question_mask"].size(-1)
+        n_txt = self.bd["question_mask"].size(-1)
         batch_dict["mmt_txt_output"], batch_dict["mmt_ocr_output"] = seq[:, :n_txt], seq[:, self.ocr0: self.ocr0 + self.n_ocr]
         batch_dict["mmt_dec_output"] = seq[:, self.n - s:]
         if self.beam:
@@ -493,13 +611,17 @@ def signature(batch_dict, beam):
     return (int(beam),) + tuple((k, kk, tuple(v.shape), v.dtype) for k, kk, v in _flatten(batch_dict))
 
 
-def session_for(model, batch_dict, beam=0, eos_idx=None):
+def shared_beams_enabled():
+    return os.environ.get("SAM_BEAM_SHARED", "1") != "0"
+
+
+def session_for(model, batch_dict, beam=0, eos_idx=None, shared=False):
     """the model's cached DecodeSession for these input shapes (a handful of shapes per run: full batches and the last partial one)"""
     cache = model.__dict__.setdefault("_sam_decode_sessions", {})
-    sig = signature(batch_dict, beam) + (eos_idx,)
+    sig = signature(batch_dict, beam) + (eos_idx, bool(shared))
     ses = cache.get(sig)
     if ses is None:
         if len(cache) >= 4:
             cache.pop(next(iter(cache)))
-        ses = cache[sig] = DecodeSession(model, batch_dict, beam, eos_idx)
+        ses = cache[sig] = DecodeSession(model, batch_dict, beam, eos_idx, shared)
     return ses

@@ -760,12 +760,23 @@ class SAM4C(_HipModule):
     def _forward_beam_search(self, batch_dict):
         """sa_m4c.py:304-314 + sam/beam_search.py: the batch is expanded beam_size times, then ONE full pass and n_dec - 1 captured decoding steps
         (decoder.DecodeSession) with sam_beam_step choosing the surviving beams on the device"""
-        from .decoder import session_for
+        from .decoder import session_for, shared_beams_enabled
         if self.training:
             raise RuntimeError("beam search runs in eval mode (evaluator.py:137-160 calls model.eval() first); call .eval()")
         if getattr(self, "bsdecoder", None) is None:
             raise RuntimeError("call set_beam_size(k) before forward(..., use_beam_search=True) (sa_m4c.py:53-56, evaluator.py:139)")
         bs = self.bsdecoder
+        if shared_beams_enabled() and bs._decode_size > 1:
+            # the beams of a sample share its encoder rows: the batch is NOT repeated beam_size times (beam_search.py:31-82), the session keeps one
+            # copy per sample (decoder.DecodeSession, shared=True); what the reference's expansion leaves in batch_dict for its callers -- the
+            # decoder state, the scores and question_id, beam_size rows per sample -- is produced all the same
+            k = bs._decode_size
+            bs.completed_ids, bs._batch_size = None, batch_dict["train_prev_inds"].shape[0]
+            ses = session_for(self, batch_dict, beam=k, eos_idx=bs._EOS_IDX, shared=True)
+            ses.run(batch_dict)
+            if "question_id" in batch_dict:
+                batch_dict["question_id"] = batch_dict["question_id"].repeat_interleave(k, dim=0)
+            return batch_dict
         batch_dict = bs.init_batch(batch_dict)
         batch_dict.pop("_beam_done", None)
         ses = session_for(self, batch_dict, beam=bs._decode_size, eos_idx=bs._EOS_IDX)

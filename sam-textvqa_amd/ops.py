@@ -163,14 +163,19 @@ def attn_fwd_rows(qkv, allow, batch, n_heads, scale, q_begin, out, lse2):
     return out
 
 
-def attn_fwd_dec(qkv_enc, qkv_dec, allow, batch, n, n_dec, n_heads, scale, out_dec=None):
+def attn_fwd_dec(qkv_enc, qkv_dec, allow, batch, n, n_dec, n_heads, scale, out_dec=None, kv_group=1):
     """decoding step: decoder rows' q|k|v in their own compact buffer qkv_dec [B*n_dec, 3*H*64], encoder rows read from the full-pass cache
-    qkv_enc [B*N, 3*H*64] -> attention output of the decoder rows [B*n_dec, H*64] (sam_attn_fwd_dec)"""
+    qkv_enc [B*N, 3*H*64] -> attention output of the decoder rows [B*n_dec, H*64] (sam_attn_fwd_dec).  kv_group > 1 (beam search): qkv_enc and
+    allow hold B / kv_group samples, each shared by kv_group consecutive decoder blocks (sam_attn_fwd_dec_shared)."""
     _chk(qkv_enc, BF16, "qkv_enc"); _chk(qkv_dec, BF16, "qkv_dec"); _chk(allow, torch.int32, "allow")
     d_model = qkv_enc.shape[1] // 3
     if out_dec is None:
         out_dec = torch.empty((batch * n_dec, d_model), dtype=BF16, device=qkv_enc.device)
     sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    if kv_group > 1:
+        capi.call("sam_attn_fwd_dec_shared", capi.ptr(qkv_enc), capi.ptr(qkv_dec), capi.ptr(allow), allow.stride(0), sh, batch, int(kv_group), n, n_dec, n_heads,
+                  d_model // n_heads, float(scale), capi.ptr(out_dec), capi.stream_handle())
+        return out_dec
     capi.call("sam_attn_fwd_dec", capi.ptr(qkv_enc), capi.ptr(qkv_dec), capi.ptr(allow), allow.stride(0), sh, batch, n, n_dec, n_heads, d_model // n_heads,
               float(scale), capi.ptr(out_dec), capi.stream_handle())
     return out_dec

@@ -417,6 +417,97 @@ def test_beam_search_whole_model_vs_oracle(beam, monkeypatch):
     assert torch.allclose(tk_g[same], tk_o[same], rtol=0.02, atol=0.05)
 
 
+@pytest.mark.parametrize("beam", [3, 5])
+def test_beams_sharing_one_copy_of_the_encoder_rows_decode_like_the_expanded_batch(beam, monkeypatch):
+    """DecodeSession(shared=True) -- first pass once per sample, sam_attn_fwd_dec_shared in the steps -- against the reference's layout (every sample repeated
+    beam_size times, SAM_BEAM_SHARED=0): the same per-row arithmetic, so the same beams, cumulative scores and final scores (GEMM tile choices differ
+    with the row count: last-bit differences, no more); outputs have beam_size rows per sample either way"""
+    model, ref, shapes = _models(layers=("n", "s"))
+    from sam_textvqa_amd.registry import registry
+    from sam_textvqa_amd.synthetic import clone_batch
+    registry.EOS_IDX, registry.BOS_IDX = 2, 1
+    bd_cpu = _batch(6, shapes, 300, 29, "cpu")
+    bd_cpu["train_prev_inds"] = torch.zeros_like(bd_cpu["train_prev_inds"]); bd_cpu["train_prev_inds"][:, 0] = 1
+    bd_cpu["question_id"] = torch.arange(6) + 10
+    model.set_beam_size(beam)
+    outs = {}
+    for shared in ("0", "1"):
+        monkeypatch.setenv("SAM_BEAM_SHARED", shared)
+        model.__dict__.pop("_sam_decode_sessions", None)
+        for rep in range(2):                                   # (second call: graph replay on the session's buffers)
+            bd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in clone_batch(bd_cpu).items()}
+            with torch.no_grad():
+                got = model(bd, use_beam_search=True)
+            cur = {k: got[k].float().cpu() for k in ("complete_seqs", "topkscores", "textvqa_scores", "question_id")}
+            if rep:
+                for k in cur:
+                    assert torch.equal(cur[k], outs[shared][k]), (shared, k)
+            outs[shared] = cur
+        ses = next(iter(model._sam_decode_sessions.values()))
+        assert ses.group == (beam if shared == "1" else 1) and ses.rows == 6 * beam
+        assert bd["train_prev_inds"].shape[0] == 6 * beam and bd["mmt_seq_output"].shape[0] == 6 * beam
+    a, b = outs["0"], outs["1"]
+    assert torch.equal(a["question_id"], b["question_id"])
+    s = shapes[3]
+    same = (a["complete_seqs"].reshape(6, beam, s) == b["complete_seqs"].reshape(6, beam, s)).all(-1).all(-1)
+    live = a["textvqa_scores"] > -9000
+    err = ((a["textvqa_scores"] - b["textvqa_scores"]).abs()[live & (b["textvqa_scores"] > -9000)].max() / a["textvqa_scores"][live].abs().max()).item()
+    print("shared vs expanded beams (k=%d): %d / 6 samples follow identical beams, score difference %.1e of max" % (beam, int(same.sum()), err))
+    assert same.sum() >= 5                                    # (a last-bit score difference may flip a near-tie)
+    tk_a, tk_b = a["topkscores"].reshape(6, beam), b["topkscores"].reshape(6, beam)
+    assert torch.allclose(tk_a[same], tk_b[same], rtol=5e-3, atol=5e-3)
+
+
+@pytest.mark.parametrize("early", [False, True])
+def test_incremental_beam_steps_decode_like_the_full_recompute(early, monkeypatch):
+    """DecodeSession._step_inc (one new decoder row per beam and step, the earlier rows' keys / values re-gathered by source beam, scores collected per
+    position and ordered through the ancestry table) against the session's full step (all decoder rows of every beam recomputed every step, as the
+    reference does): same beams, cumulative scores and per-position scores.  early: the EOS logit is raised so that every beam completes after a few
+    steps -- the search must stop there (sam_beam_step's finished flag), later replays must leave the result alone"""
+    model, ref, shapes = _models(layers=("n", "s"))
+    from sam_textvqa_amd.registry import registry
+    from sam_textvqa_amd.synthetic import clone_batch
+    eos, beam, s = 2, 5, shapes[3]
+    registry.EOS_IDX, registry.BOS_IDX = eos, 1
+    bd_cpu = _batch(6, shapes, 300, 31, "cpu")
+    if early:       # EOS is the only candidate worth taking (every other answer 60 logits down, no OCR token valid): all beams are complete after step 1
+        model.classifier.bias.data -= 60.0                 # (the previous token's own logit is large in a random model: 60 puts it out of reach)
+        model.classifier.bias.data[eos] += 120.0
+        bd_cpu["pad_ocr_mask"] = torch.zeros_like(bd_cpu["pad_ocr_mask"])
+    bd_cpu["train_prev_inds"] = torch.zeros_like(bd_cpu["train_prev_inds"]); bd_cpu["train_prev_inds"][:, 0] = 1
+    model.set_beam_size(beam)
+    outs = {}
+    for inc in ("0", "1"):
+        monkeypatch.setenv("SAM_BEAM_INCREMENTAL", inc)
+        for graph in ("1", "0"):
+            monkeypatch.setenv("SAM_DECODE_GRAPH", graph)
+            model.__dict__.pop("_sam_decode_sessions", None)
+            bd = {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in clone_batch(bd_cpu).items()}
+            with torch.no_grad():
+                got = model(bd, use_beam_search=True)
+            cur = {k: got[k].float().cpu() for k in ("complete_seqs", "topkscores", "textvqa_scores")}
+            cur["dec"] = bd["mmt_dec_output"].float().cpu()
+            if graph == "0":
+                for k in cur:
+                    assert torch.equal(cur[k], outs[inc][k]), (inc, k)           # replayed graphs == launch by launch
+            outs[inc] = cur
+        assert next(iter(model._sam_decode_sessions.values())).incremental == (inc == "1")
+    a, b = outs["0"], outs["1"]
+    seq_a, seq_b = a["complete_seqs"].reshape(6, beam, s), b["complete_seqs"].reshape(6, beam, s)
+    same = (seq_a == seq_b).all(-1).all(-1)
+    if early:
+        assert (seq_a[:, :, 1:3] == eos).any(-1).all() and (seq_a[:, :, 3:] == 0).all(), "the search did not end after step 1"
+    npos = 2 if early else s                                  # (after an early end the later positions are not part of the search)
+    rows = same.repeat_interleave(beam)
+    sa, sb = a["textvqa_scores"][rows][:, :npos], b["textvqa_scores"][rows][:, :npos]
+    live = (sa > -9000) & (sb > -9000)
+    err = ((sa - sb).abs()[live].max() / sa[live].abs().max()).item()
+    derr = ((a["dec"][rows][:, :npos] - b["dec"][rows][:, :npos]).abs().max() / a["dec"].abs().max()).item()
+    print("incremental vs full beam steps (early=%s): %d / 6 samples identical beams, scores %.1e, decoder rows %.1e of max" % (early, int(same.sum()), err, derr))
+    assert same.sum() >= 5 and err < 6e-3 and derr < 3e-2
+    assert torch.allclose(a["topkscores"].reshape(6, beam)[same], b["topkscores"].reshape(6, beam)[same], rtol=5e-3, atol=5e-3)
+
+
 def test_beam_search_module_api_mirrors_the_reference():
     """BeamSearch.init_batch / decode used the reference's way (sa_m4c.py:304-314) on a batch_dict with `scores`"""
     from sam_textvqa_amd.decoder import BeamSearch
