@@ -83,6 +83,12 @@ int sam_attn_fwd_dec(const void* qkv_enc, const void* qkv_dec, const uint32_t* a
  * decoder blocks.  group = 1 is sam_attn_fwd_dec. */
 int sam_attn_fwd_dec_shared(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int group,
                             int N, int n_dec, int H, int head_dim, float scale, void* out_dec, void* stream);
+/* ... and for ONE decoder row: out[b, :] (bf16, row stride ldo) = the attention output of decoder row t of decoder sample b against its sample's
+ * first N - n_dec cached rows and its own decoder rows 0..t (qkv_dec, which holds row t's q|k|v already).  What a beam-search step needs when the
+ * earlier decoder rows of a beam are kept and re-gathered instead of recomputed; one block per (sample, head) stages the shared keys / values once for
+ * all `group` beams.  fp32 arithmetic on the bf16 cache values; a row with no allowed key gives zeros. */
+int sam_attn_dec_row(const void* qkv_enc, const void* qkv_dec, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int group, int N,
+                     int n_dec, int t, int H, int head_dim, float scale, void* out, int64_t ldo, void* stream);
 /* training forward: sam_attn_fwd plus out_lo bf16 [B*N, H*64] = bf16(out_exact - bf16(out_exact)), the rounding residual of the output.  The one-pass
  * backward takes delta = rowsum(dO * O) from out + out_lo (exact to 2^-17; the bf16 output alone costs 3e-3 of max in dQ / dK), which is what lets it
  * compute every score once instead of running a row pass for delta first.  Replaces sam/sa_m4c.py:563-598 as sam_attn_fwd does. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "sam_input_encoder_bwd": [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _f, _u64, _u64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp, _vp],
     "sam_attn_fwd_dec": [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _f, _vp, _vp],
     "sam_attn_fwd_dec_shared": [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _f, _vp, _vp],
+    "sam_attn_dec_row": [_vp, _vp, _vp, _i64, _i64, _i, _i, _i, _i, _i, _i, _i, _f, _vp, _i64, _vp],
     "sam_greedy_pick": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _vp, _vp],
     "sam_beam_step": [_vp, _i64, _vp, _i64, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp],
     "sam_greedy_decode_ws_bytes": [_i, _i, _i],

@@ -420,8 +420,12 @@ class DecodeSession:
             d3 = cur.shape[1]
             torch.index_select(cur.view(r, s * d3), 0, self.prev_pos, out=nxt.view(r, s * d3))
             ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv, out=nxt.view(r, s, d3)[:, t])
-            ctx = ops.attn_fwd_dec(qkv_full, nxt, bits, r, self.n, s, att.num_attention_heads, 1.0 / math.sqrt(att.attention_head_size), kv_group=k)
-            x = _layer_tail(layer, ctx.view(r, s, -1)[:, t], x)
+            scale = 1.0 / math.sqrt(att.attention_head_size)
+            if os.environ.get("SAM_ATTN_DEC_ROW", "1") != "0":
+                ctx_t = ops.attn_dec_row(qkv_full, nxt, bits, r, self.n, s, t, att.num_attention_heads, scale, kv_group=k)
+            else:               # (the strip kernel over all decoder rows of every beam; row t of its output)
+                ctx_t = ops.attn_fwd_dec(qkv_full, nxt, bits, r, self.n, s, att.num_attention_heads, scale, kv_group=k).view(r, s, -1)[:, t]
+            x = _layer_tail(layer, ctx_t, x)
         self.y_hist[:, t] = x
         fixed_t, dyn_t = self._head(x, self.ptr_k, self.ocr_mask, r, 1)
         fixed, dyn = self.out_first

@@ -189,6 +189,18 @@ def greedy_pick(fixed, ocr, prev_inds):
     return prev_inds
 
 
+def attn_dec_row(qkv_enc, qkv_dec, allow, batch, n, n_dec, t, n_heads, scale, kv_group=1):
+    """attention output of decoder row t only, bf16 [B, H*64] (sam_attn_dec_row): qkv_enc [B/kv_group * N, 3*H*64] cached by the full pass, qkv_dec
+    [B*n_dec, 3*H*64] with rows 0..t of every decoder sample valid"""
+    _chk(qkv_enc, BF16, "qkv_enc"); _chk(qkv_dec, BF16, "qkv_dec"); _chk(allow, torch.int32, "allow")
+    d_model = qkv_enc.shape[1] // 3
+    out = torch.empty((batch, d_model), dtype=BF16, device=qkv_enc.device)
+    sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    capi.call("sam_attn_dec_row", capi.ptr(qkv_enc), capi.ptr(qkv_dec), capi.ptr(allow), allow.stride(0), sh, batch, int(kv_group), n, n_dec, int(t), n_heads,
+              d_model // n_heads, float(scale), capi.ptr(out), out.stride(0), capi.stream_handle())
+    return out
+
+
 def beam_step(fixed, ocr, n_samples, beam, seqs, cum, done, eos, t=0, ctl=None, prev_pos=None):
     """one BeamSearch.decode step (sam_beam_step), state (seqs int64 [B*K, S], cum f32 [B*K], done u8 [B*K]) updated in place"""
     _chk(seqs, torch.int64, "seqs"); _chk(cum, torch.float32, "cum"); _chk(done, torch.uint8, "done")

@@ -112,6 +112,53 @@ def test_attn_fwd_dec_equals_the_full_kernel_on_decoder_rows():
             assert torch.equal(got.view(b, n_dec, -1), full.view(b, n, -1)[:, n - n_dec:])
 
 
+def test_single_row_decode_attention_against_the_oracle_arithmetic_and_the_strip_kernel():
+    """sam_attn_dec_row (one new decoder row per beam, `group` beams sharing a sample's cached rows): against fp64 softmax(q k^T * scale + mask) v on the
+    same bf16 values at 1e-3 of max + 1 bf16 ulp (the per-kernel bound of tests/util.py), and against row t of sam_attn_fwd_dec_shared; garbage in the
+    decoder rows after position t and in the cache's own decoder rows is never read; a fully masked row gives zeros"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(6)
+    for (b0, k, n, n_dec, h) in ((3, 5, 182, 12, 12), (2, 3, 350, 30, 12), (4, 1, 40, 5, 12), (1, 8, 100, 9, 12)):
+        b, n_enc = b0 * k, n - n_dec
+        enc = torch.randn(b0 * n, 3 * h * 64, generator=g).to(torch.bfloat16).cuda()
+        dec = torch.randn(b * n_dec, 3 * h * 64, generator=g).to(torch.bfloat16).cuda()
+        kv = torch.ones(b0, n_enc, dtype=torch.uint8); kv[0, 5:9] = 0
+        allow = ops.mask_bits_prefix_lm(kv.cuda(), n_dec)
+        rel = (torch.rand(b0, h, n, n, generator=g) > 0.4).to(torch.int8)
+        rel[0, 3, n_enc + 1] = 0                                                       # (sample 0, head 3: decoder row 1 sees nothing)
+        bits_h = ops.mask_bits_from_int8_bhnn(rel.cuda(), allow)
+        for bits, per_head in ((allow, False), (bits_h, True)):
+            for t in sorted({0, 1, n_dec // 2, n_dec - 1}):
+                strip = ops.attn_fwd_dec(enc, dec, bits, b, n, n_dec, h, 0.125, kv_group=k).view(b, n_dec, h, 64)[:, t].float().cpu()
+                poisoned = dec.clone()
+                poisoned.view(b, n_dec, -1)[:, t + 1:] = float("nan")                  # later positions are masked: never read
+                cache = enc.clone()
+                cache.view(b0, n, -1)[:, n_enc:] = float("nan")
+                got = ops.attn_dec_row(cache, poisoned, bits, b, n, n_dec, t, h, 0.125, kv_group=k).view(b, h, 64).float().cpu()
+                # fp64 reference on the same values
+                e3, d3 = enc.double().cpu().view(b0, n, 3, h, 64), dec.double().cpu().view(b, n_dec, 3, h, 64)
+                words = bits.cpu().view(b0, -1, n, bits.shape[-1])
+                keys = torch.arange(n)
+                ok_all = ((words[..., n_enc + t, :][..., keys // 32] >> (keys % 32)) & 1).bool()      # [b0, H or 1, n]
+                want = torch.zeros(b, h, 64, dtype=torch.float64)
+                for bb in range(b):
+                    s0 = bb // k
+                    kk = torch.cat([e3[s0, :n_enc, 1], d3[bb, :, 1]], 0)                # [n, h, 64]
+                    vv = torch.cat([e3[s0, :n_enc, 2], d3[bb, :, 2]], 0)
+                    for hh in range(h):
+                        ok = ok_all[s0, hh if per_head else 0]
+                        if not ok.any():
+                            continue
+                        sc = (kk[:, hh] @ d3[bb, t, 0, hh]) * 0.125
+                        p = torch.softmax(sc.masked_fill(~ok, float("-inf")), 0)
+                        want[bb, hh] = p @ vv[:, hh]
+                tol = 1e-3 * want.abs().max().item() + 2.0 ** -8 * want.abs()
+                assert torch.isfinite(got).all() and bool(((got.double() - want).abs() <= tol).all()), (b0, k, n, t, (got.double() - want).abs().max().item())
+                assert (got - strip).abs().max().item() <= 2e-3 * strip.abs().max().item() + 2.0 ** -7 * strip.abs().max().item()
+                if per_head and t == 1:
+                    assert (got[:k, 3] == 0).all() and (want[:k, 3] == 0).all()         # the fully masked row of sample 0's beams
+
+
 def _models(layers=("n", "s", "s"), vocab=300):
     from sam_textvqa_amd.params import prepare
     from tests.test_model_gpu import _small_full_model
