@@ -370,7 +370,7 @@ def dist_one_rank(args):
     import subprocess
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, SAM_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "30", "--warmup", "6", "--batch", str(args.batch), "--context", str(args.context),
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "60", "--warmup", "8", "--batch", str(args.batch), "--context", str(args.context),
            "--vocab", str(args.vocab), "--shape", args.shape, "--no-eager-baseline", "--no-cpu-baseline", "--no-roofline", "--no-secondary"]
     try:
         r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
@@ -378,7 +378,7 @@ def dist_one_rank(args):
         if r.returncode != 0 or not line:
             return {"error": (r.stderr or r.stdout)[-300:]}
         d = json.loads(line[-1])
-        return {k: d.get(k) for k in ("value", "ms_per_step", "exposed_comm_ms", "overlap", "grad_payload", "step_mode")}
+        return {k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "slow_steps", "exposed_comm_ms", "overlap", "grad_payload", "step_mode", "rccl_ranks_seen")}
     except Exception as e:
         return {"error": str(e)[:200]}
 
