@@ -378,7 +378,14 @@ def dist_one_rank(args):
         if r.returncode != 0 or not line:
             return {"error": (r.stderr or r.stdout)[-300:]}
         d = json.loads(line[-1])
-        return {k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "slow_steps", "exposed_comm_ms", "overlap", "grad_payload", "step_mode", "rccl_ranks_seen")}
+        out = {k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "slow_steps", "exposed_comm_ms", "overlap", "grad_payload", "step_mode", "rccl_ranks_seen")}
+        # the same captured step with the collectives AFTER the backward instead of underneath it: replayed graph against replayed graph
+        r2 = subprocess.run(cmd + ["--no-overlap"], env=dict(env, MASTER_PORT=str(port + 1)), capture_output=True, text=True, timeout=600, cwd=ROOT)
+        line2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
+        if r2.returncode == 0 and line2:
+            d2 = json.loads(line2[-1])
+            out["no_overlap"] = {k: d2.get(k) for k in ("ms_per_step", "ms_per_step_median", "overlap", "step_mode")}
+        return out
     except Exception as e:
         return {"error": str(e)[:200]}
 
@@ -413,13 +420,9 @@ def main():
     shape = SHAPES[args.shape]
     layers = ("n", "n", "s", "s", "s", "s") if args.shape == "c3" else ("n", "n") + ("s",) * 10
     model = build_model(args.context, layers, args.vocab, shape)
-    reducer = None
-    if world > 1 and args.no_overlap:
-        from sam_textvqa_amd.params import prepare
-        groups = model.get_optimizer_parameters(1e-4)
-        flat = prepare(model, groups=[g["params"] for g in groups])
-        reducer = parallel.GradReducer(flat.grad, overlap=False)
-    trainer = Trainer(model, seed=1234 + rank, use_graph=not args.no_graph, reducer=reducer)      # (N > 1: captured too when the collectives are RCCL's, trainer._dp_capturable)
+    # (N > 1, or a 1-rank group under SAM_FORCE_DIST=1: the Trainer builds the reducer -- bucketed all-reduce at the regions' finality marks + row-sparse table
+    # exchange; --no-overlap: the same reducer with its collectives on the step's own stream after the backward, captured all the same)
+    trainer = Trainer(model, seed=1234 + rank, use_graph=not args.no_graph, overlap=not args.no_overlap)
     trainer.measure_comm = trainer.reducer is not None        # (N > 1, or a 1-rank group under SAM_FORCE_DIST=1)
     batch = make_batch(args.batch, *shape, vocab=args.vocab, context=args.context, device=dev, seed=1234 + rank)
     # The step's work depends on its input VALUES in one place: the row-sparse word-embedding table (norm + Adam walk only rows that ever received a

@@ -30,7 +30,7 @@ def masked_bce_loss(batch_dict, grad_scale=1.0, unit_grad=False, global_count=No
 
 class Trainer:
     def __init__(self, model, base_lr=1e-4, max_grad_norm=0.25, betas=(0.9, 0.999), eps=1e-8, schedule=None, reducer=None, seed=0, use_graph=None,
-                 pipeline_update=None):
+                 pipeline_update=None, overlap=True):
         self.model = model
         self.base_lr = base_lr
         groups = model.get_optimizer_parameters(base_lr)
@@ -46,7 +46,7 @@ class Trainer:
         self.schedule = schedule or {}
         dist = parallel.dist
         if reducer is None and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SAM_FORCE_DIST") == "1"):
-            reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range())
+            reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range(), overlap=overlap)      # (overlap=False: buckets leave after the backward, an A/B)
         self.reducer = reducer
         rank = dist.get_rank() if dist.is_initialized() else 0
         if reducer is not None and dist.is_initialized():
@@ -272,9 +272,10 @@ class Trainer:
         """the data-parallel step is captured like the single-GPU one -- ONE step for every N -- when its collectives can be: RCCL ("nccl") all-reduce /
         all-gather calls are stream-capturable and the order in which the buckets leave is fixed once the regions are registered, so the captured
         graph holds the forward, the backward with the bucket all-reduces forked onto the reducer's stream at their finality points, the join, clip
-        and Adam.  Not capturable: gloo (CPU-mediated: the 2-rank CPU / shared-GPU tests), the reducer's self-check (host comparisons), SAM_DP_GRAPH=0."""
+        and Adam.  Not capturable: gloo (CPU-mediated: the 2-rank CPU / shared-GPU tests), the reducer's self-check (host comparisons), SAM_DP_GRAPH=0.  (A reducer without overlap is
+        captured too -- its collectives are enqueued on the step's own stream: the A/B of the overlap is then between two replayed graphs.)"""
         red = self.reducer
-        if os.environ.get("SAM_DP_GRAPH", "1") == "0" or red.check or not red.overlap or not parallel.dist.is_initialized():
+        if os.environ.get("SAM_DP_GRAPH", "1") == "0" or red.check or not parallel.dist.is_initialized():
             return False
         try:
             return parallel.dist.get_backend(red.group) == "nccl"

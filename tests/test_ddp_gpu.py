@@ -172,13 +172,13 @@ from sam_textvqa_amd.trainer import Trainer
 os.environ["SAM_FORCE_DIST"] = "1"
 parallel.init_distributed()                               # 1-rank RCCL group
 res = []
-for mode in ("dp_graph", "dp_eager", "plain_graph"):
+for mode in ("dp_graph", "dp_eager", "plain_graph", "dp_graph_no_overlap"):
     os.environ["SAM_FORCE_DIST"] = "0" if mode == "plain_graph" else "1"
     model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
-    tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=mode != "dp_eager")
+    tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=mode != "dp_eager", overlap=mode != "dp_graph_no_overlap")
     assert (tr.reducer is not None) == (mode != "plain_graph")
-    if mode == "dp_graph":
-        assert tr._dp_capturable()
+    if mode.startswith("dp_graph"):
+        assert tr._dp_capturable() and tr.reducer.overlap == (mode == "dp_graph")
     batch = make_batch(4, vocab=300, device="cuda", seed=21)
     batch["question_indices"] = batch["question_indices"] % 500
     losses = [tr.step(clone_batch(batch)).item() for _ in range(6)]
@@ -189,11 +189,11 @@ for mode in ("dp_graph", "dp_eager", "plain_graph"):
     tr.flush_update()                                                      # (captured steps leave their update pending)
     res.append((losses, tr.flat.flat.clone()))
 torch.cuda.synchronize()
-(lg, pg), (le, pe), (lp, pp) = res
-print("LOSSES", lg, le, lp)
-for other in (le, lp):
+(lg, pg), (le, pe), (lp, pp), (ln, pn) = res
+print("LOSSES", lg, le, lp, ln)
+for other in (le, lp, ln):
     assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(lg, other)), (lg, other)
-assert (pg - pe).abs().max().item() < 7e-3 and (pg - pp).abs().max().item() < 7e-3
+assert (pg - pe).abs().max().item() < 7e-3 and (pg - pp).abs().max().item() < 7e-3 and (pg - pn).abs().max().item() < 7e-3
 print("GRAPH_DP_OK")
 """
 
