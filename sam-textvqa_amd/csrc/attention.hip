@@ -549,103 +549,7 @@ int fill_common(AttnArgs& a, int B, int N, int H, int head_dim, float scale, flo
 namespace {
 
 // threads per block: long sequences (16 / 24 key tiles: the stress shape's 350 tokens) need 64-96 KB of LDS per block, i.e. ONE block per CU, and
-// run 8 waves (two per SIMD); 12 key tiles (N = 182) run SAM_ATTN_FWD_NT threads (default 512; 384 = two strips per wave, three blocks per CU)
-// ---- 12 key tiles (129 .. 192 tokens: the c3 / c5 shapes), full forward: THREE heads per block, one block per CU ------------------------
-// 768 (batch, head) pairs at two blocks per CU are one and a half rounds: the second round runs half empty (PMC: 42 % of the wave cycles parked),
-// and inside a block twelve strips over eight waves leave four waves idle for half the time.  Here a block of TWELVE waves owns three heads
-// (3 x 48 KB of K / V tiles = 144 KB: the CU's LDS), wave w computes strip w of each head -- one launch round at B = 64, every wave the same work --
-// and the tiles of head j+1 are requested into registers before head j is computed (converted and written to their own LDS region afterwards),
-// so the load phase of a head is covered by the previous head's arithmetic.
-constexpr int FWD3_HEADS = 3;
-template <bool DROP>
-__global__ __launch_bounds__(768) void attn_fwd3_kernel(AttnArgs a) {
-  constexpr int NKT = 12, NPAD = NKT * 16, NT = 768, NWV = 12, PER = NPAD * 8 / NT, TILE = NPAD * ROW_BYTES;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned* red = reinterpret_cast<unsigned*>(smem + 2 * FWD3_HEADS * TILE);      // [NWV]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, g = lane >> 4;
-  const int N = a.N, Dm = a.H * HD, BH = a.B * a.H;
-  const int64_t ld = 3 * (int64_t)Dm;
-  const int bh0 = blockIdx.x * FWD3_HEADS;
-  const int q = wave * 16 + i, qc = q < N ? q : N - 1;
-
-  uint4 kreg[PER], vreg[PER];
-  bf16x8 qf_n[2];
-  unsigned naw_n[NKT / 2];
-  auto request = [&](int bh) {                 // K / V chunks of the head's tiles, this wave's query rows and allow words (all unconditional, clamped)
-    const int b = bh / a.H, h = bh - b * a.H;
-    const bf16_t* qbase = a.qkv + (int64_t)b * N * ld + h * HD;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      const int c = tid + j * NT, row = c >> 3, ch = c & 7, rc = row < N ? row : N - 1;
-      kreg[j] = *reinterpret_cast<const uint4*>(qbase + Dm + (int64_t)rc * ld + ch * 8);
-      vreg[j] = *reinterpret_cast<const uint4*>(qbase + 2 * Dm + (int64_t)rc * ld + ch * 8);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) qf_n[ks] = *reinterpret_cast<const bf16x8*>(qbase + (int64_t)qc * ld + 32 * ks + 8 * g);
-    const uint32_t* ap = a.allow + b * a.allow_sb + h * a.allow_sh + (int64_t)qc * a.NW;
-#pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) naw_n[w] = ap[w];
-  };
-  unsigned seed_lo = a.seed_lo, seed_hi = a.seed_hi, off_lo = a.off_lo, off_hi = a.off_hi;
-  if (DROP) rng_resolve(a.rng_state, seed_lo, seed_hi, off_lo, off_hi);
-  const unsigned thr2 = ((a.thr16 ^ 0x8000u) & 0xffffu) * 0x00010001u;
-  const unsigned nibmask = 0x000F000Fu << (4 * g);
-
-  request(bh0 < BH ? bh0 : BH - 1);
-#pragma unroll 1
-  for (int j = 0; j < FWD3_HEADS; ++j) {
-    const int bh = bh0 + j;
-    if (bh >= BH) break;                        // (block-uniform)
-    const int b = bh / a.H, h = bh - b * a.H;
-    unsigned char* Ks = smem + (2 * j) * TILE;
-    unsigned char* Vs = Ks + TILE;
-    // ---- the requested tiles: K as it is, V as block-scaled fp16
-    unsigned vmax = 0;
-#pragma unroll
-    for (int x = 0; x < PER; ++x) {
-      const int c = tid + x * NT, row = c >> 3, ch = c & 7;
-      if (row >= N) { kreg[x] = make_uint4(0, 0, 0, 0); vreg[x] = kreg[x]; }
-      *reinterpret_cast<uint4*>(Ks + tile_off(row, ch)) = kreg[x];
-      vmax = absmax_acc4(vmax, vreg[x]);
-    }
-    vmax = wave_max_u32(absmax_fold(vmax));
-    if (lane == 0) red[wave] = vmax;
-    __syncthreads();
-    unsigned bmax = 0;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) bmax = red[w] > bmax ? red[w] : bmax;
-    const int cv = scale_c_of(bmax);
-    const unsigned csub = csub_of(cv);
-#pragma unroll
-    for (int x = 0; x < PER; ++x) {
-      const int c = tid + x * NT;
-      *reinterpret_cast<uint4*>(Vs + tile_off(c >> 3, c & 7)) = bf2h_pk4(vreg[x], csub);
-    }
-    bf16x8 qf[2] = {qf_n[0], qf_n[1]};
-    unsigned naw[NKT / 2];
-#pragma unroll
-    for (int w = 0; w < NKT / 2; ++w) naw[w] = ~naw_n[w] >> (4 * g);
-    __syncthreads();                            // (also: every wave has read red[] before the next head overwrites it)
-    if (j + 1 < FWD3_HEADS && bh + 1 < BH) request(bh + 1);        // in flight while this head is computed
-    __builtin_amdgcn_sched_barrier(0);
-    if (wave * 16 < N)
-      attn_fwd_strip<NKT, false, DROP>(a, Ks, Vs, qf, naw, bh, b, h, q, qc, N, Dm, i, g, ldexpf(a.inv_keep, cv - 112), thr2, nibmask, seed_lo, seed_hi, off_lo, off_hi);
-  }
-}
-
-template <bool DROP>
-int launch_fwd3(const AttnArgs& a, hipStream_t st) {
-  const size_t lds = (size_t)2 * FWD3_HEADS * 12 * 16 * ROW_BYTES + 64;
-  static bool once = false;
-  if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd3_kernel<DROP>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    once = true;
-  }
-  attn_fwd3_kernel<DROP><<<dim3((a.B * a.H + FWD3_HEADS - 1) / FWD3_HEADS), dim3(768), lds, st>>>(a);
-  SAM_LAUNCH_CHECK();
-  return SAM_OK;
-}
-
+// run 8 waves (two per SIMD); 12 key tiles (N = 182) run 512 threads, two blocks per CU
 template <int NKT, bool DEC, bool DROP, int NT>
 int launch_fwd_nt(const AttnArgs& a, hipStream_t st) {
   const size_t lds = (size_t)2 * NKT * 16 * ROW_BYTES + 64;
@@ -659,38 +563,17 @@ int launch_fwd_nt(const AttnArgs& a, hipStream_t st) {
   return SAM_OK;
 }
 
-int fwd_nt12() {
-  static int nt = -1;
-  if (nt < 0) {
-    const char* e = getenv("SAM_ATTN_FWD_NT");
-    nt = e ? atoi(e) : 512;
-    if (nt != 256 && nt != 384 && nt != 512) nt = 512;
-  }
-  return nt;
-}
-
+// 12 key tiles (N = 182): 512 threads, two blocks per CU.  Measured and dropped in round 4 (profiles/r4m_micro_attn.txt, git history of this file): 256 / 384
+// threads per block (slower by 4-9 %), and a 12-wave block owning THREE heads with the next head's tiles prefetched (one launch round instead of one and a
+// half at B = 64: 30.5 us against 28.6 -- twelve waves in lock step hide less latency than two independent 8-wave blocks).
 template <int NKT, bool DEC, bool DROP>
 int launch_fwd_d(const AttnArgs& a, hipStream_t st) {
-  if (NKT == 12) {
-    switch (fwd_nt12()) {
-      case 256: return launch_fwd_nt<12, DEC, DROP, 256>(a, st);
-      case 384: return launch_fwd_nt<12, DEC, DROP, 384>(a, st);
-      default: return launch_fwd_nt<12, DEC, DROP, 512>(a, st);
-    }
-  }
   return launch_fwd_nt<NKT, DEC, DROP, (NKT <= 2 ? 128 : NKT <= 8 ? 256 : 512)>(a, st);
 }
 
 template <bool DEC>
 int launch_fwd_any(const AttnArgs& a, hipStream_t st) {
   const bool drop = !DEC && a.thr16 != 0;
-  if (!DEC && a.nkt == 12 && a.q_begin == 0 && a.B * a.H >= 2 * FWD3_HEADS) {
-    // opt-in: measured 30.5 us against 28.6 us for the one-head blocks (c3, B = 64, dropout on, with the residual output; profiles/r4*_micro_attn.txt):
-    // twelve waves in lock step per CU hide less latency than two independent 8-wave blocks, which costs more than the half-empty second round returns
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("SAM_ATTN_FWD3"); on = (e && e[0] == '1') ? 1 : 0; }
-    if (on) return drop ? launch_fwd3<true>(a, st) : launch_fwd3<false>(a, st);
-  }
 #define SAM_FWD_CASE(K) case K: return drop ? launch_fwd_d<K, DEC, !DEC>(a, st) : launch_fwd_d<K, DEC, false>(a, st);
   switch (a.nkt) {
     SAM_FWD_CASE(2) SAM_FWD_CASE(4) SAM_FWD_CASE(8) SAM_FWD_CASE(12) SAM_FWD_CASE(16) SAM_FWD_CASE(24)

@@ -97,35 +97,16 @@ __device__ __forceinline__ void rng_resolve(const unsigned long long* st, unsign
   }
 }
 
-// Philox4x32-10 (Salmon et al. 2011), counter-based: same (key, counter) -> same bits in fwd and bwd.
 struct u32x4 { unsigned x, y, z, w; };
-__device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-    unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-    unsigned n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-    c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  return {c0, c1, c2, c3};
-}
-// Attention-probability dropout draws 8 x 16 random bits per (row, 32-key slab, lane group): Philox there costs as much VALU
-// as the whole softmax (measured +15 us on a 40 us kernel).  A counter-based integer hash (two multiplies + three xorshifts per
-// 32 bits, "lowbias32" finaliser) of the same (counter, key) tuple gives statistically clean keep masks at a third of the cost;
-// the hidden-state dropout in the GEMM epilogue / LayerNorm backward keeps Philox (one call per 8 elements, negligible there).
+// Counter-based dropout bits: same (seed, offset, row, column group) -> same bits in the forward and in the backward pass.
 __device__ __forceinline__ unsigned mix32(unsigned x) {
   x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
   return x;
 }
-__device__ __forceinline__ u32x4 dropout_bits128(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
-  const unsigned base = mix32(c0 * 0x9E3779B1u + (c2 ^ k0)) ^ (c1 * 0x85EBCA77u + c3 * 0xC2B2AE3Du + k1);
-  return {mix32(base), mix32(base + 0x68E31DA4u), mix32(base + 0xB5297A4Du), mix32(base + 0x1B56C4E9u)};
-}
 // Round-4 generator: the expensive mixing (mix32: two 32-bit multiplies) happens once per ROW (dropout_row_key; loop-invariant wherever a thread or wave stays
 // on one row: the attention strips, the LayerNorm backward, the GEMM epilogue's row loop); a draw of 8 x 16 bits for (row, column group) then costs full-rate
-// operations only -- two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24) around xor-shifts per 32-bit word.  dropout_bits128 above spends 13 quarter-rate
-// 32-bit multiplies per draw: a fifth of the attention forward's VALU time, 3 us of a 17 us LayerNorm backward.  Keep rate, independence across rows / columns /
+// operations only -- two 24-bit multiplies (v_mul_u32_u24 / v_mad_u32_u24) around xor-shifts per 32-bit word.  The generator of rounds 1-3 (four lowbias32 mixes per draw: 13 quarter-rate
+// 32-bit multiplies) was a fifth of the attention forward's VALU time and 3 us of a 17 us LayerNorm backward.  Keep rate, independence across rows / columns /
 // heads / samples / offsets / seeds, avalanche and a duplicate census were checked on the CPU against the old generator (tools/debug/hash_eval.py) and are
 // tested on the device (tests/test_attention_gpu.py::test_dropout_streams_are_independent_...).
 __device__ __forceinline__ unsigned dropout_row_key(unsigned row, unsigned off_lo, unsigned off_hi, unsigned seed_lo, unsigned seed_hi) {

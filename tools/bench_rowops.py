@@ -20,3 +20,6 @@ dg, db, dbias = torch.zeros(D, device="cuda"), torch.zeros(D, device="cuda"), to
 u = t(lambda i: ops.layernorm_fwd(xs[i], g, b, 1e-12)); print("ln_fwd          %.1f us  %.0f GB/s" % (u, 2 * M * D * 2 / u / 1e3))
 u = t(lambda i: ops.layernorm_bwd(dys[i], xs[i], mean, rstd, g, dg, db, dbias, want_dropped=True, p_drop=0.1, seed=1, offset=1)); print("ln_bwd(+drop)   %.1f us  %.0f GB/s" % (u, 4 * M * D * 2 / u / 1e3))
 u = t(lambda i: ops.layernorm_bwd(dys[i], xs[i], mean, rstd, g, dg, db, dbias, want_dropped=True, p_drop=0.0)); print("ln_bwd(no drop) %.1f us  %.0f GB/s" % (u, 3 * M * D * 2 / u / 1e3))
+# the same traffic as a plain strided copy (sam_copy_blocks: 2 x 18 MB in, 2 x 18 MB out): what a kernel that only moves the bytes gets at this size
+outs = [torch.empty(M, D * 2, device="cuda", dtype=torch.bfloat16) for _ in range(SETS)]
+u = t(lambda i: ops.copy_blocks([(xs[i].view(1, M, D), outs[i][:, :D].unsqueeze(0)), (dys[i].view(1, M, D), outs[i][:, D:].unsqueeze(0))])); print("copy 2x18 MB    %.1f us  %.0f GB/s" % (u, 4 * M * D * 2 / u / 1e3))
