@@ -123,6 +123,17 @@ int sam_attn_bwd(const void* dout, const void* qkv, const float* lse2, const uin
  *   SAM_EPI_MUL_AUX           C = acc * aux_in[m,n]                               backward of BertIntermediate from the stored derivative
  * bias may be NULL (treated as 0); dropout draws 8 x 16 bits per (row, col/8) from the counter hash so the backward regenerates it. */
 enum { SAM_EPI_NONE = 0, SAM_EPI_BIAS = 1, SAM_EPI_BIAS_GELU = 2, SAM_EPI_BIAS_DROPOUT_RES = 3, SAM_EPI_DGELU = 4, SAM_EPI_BIAS_GELU_GRAD = 5, SAM_EPI_MUL_AUX = 6 };
+/* Optional LayerNorm behind a GEMM whose epilogue is SAM_EPI_BIAS_DROPOUT_RES with a bf16 output (BertSelfOutput / BertOutput, sam/sa_m4c.py:653,680 +
+ * 1016-1028: LayerNorm(dropout(x W^T + b) + residual)).  When the library runs such a GEMM split over K (skinny M, long K), the pass that sums the partials
+ * and applies the epilogue owns whole rows and normalises them on the spot: C receives the pre-LayerNorm sums as ever (the backward reads them), y / mean /
+ * rstd what sam_layernorm_fwd would have produced from C, bit for bit; `done` is set to 1.  In every other case `done` is set to 0 and the caller runs
+ * sam_layernorm_fwd itself.  N % 4 == 0, N <= 2048. */
+typedef struct sam_ln_fuse {
+  const float* gamma; const float* beta; float eps;
+  void* y; int64_t ldy;          /* bf16 [M, N] */
+  float* mean; float* rstd;      /* fp32 [M] */
+  int32_t done;                  /* OUT */
+} sam_ln_fuse;
 typedef struct sam_gemm_desc {
   int32_t M, N, K;
   int32_t a_kcontig, b_kcontig;
@@ -145,6 +156,7 @@ typedef struct sam_gemm_desc {
                          persistent kernel with 192x192 / 256x256 / 192x256 tiles (testing, tuning) */
   int32_t defer_reduce;  /* split-K only: 1 = leave the partials in ws and let the caller run sam_gemm_splitk_reduce (separately timeable) */
   int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
+  sam_ln_fuse* ln;       /* optional (NULL = none): see sam_ln_fuse */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
 /* up to 12 independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C, SAM_EPI_NONE, no split) in ONE grid: the four

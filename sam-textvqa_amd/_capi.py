@@ -10,6 +10,11 @@ LIB_PATH = os.path.join(_PKG, "lib", "libsam_hip.so")
 
 _vp, _i, _i64, _u64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_uint
 
+class LnFuse(C.Structure):
+    """mirror of `sam_ln_fuse` (include/sam_hip.h)"""
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("eps", _f), ("y", _vp), ("ldy", _i64), ("mean", _vp), ("rstd", _vp), ("done", C.c_int32)]
+
+
 class GemmDesc(C.Structure):
     """mirror of `sam_gemm_desc` (include/sam_hip.h)"""
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
@@ -19,7 +24,7 @@ class GemmDesc(C.Structure):
                 ("bias", _vp), ("residual", _vp), ("ldr", _i64),
                 ("aux_out", _vp), ("aux_in", _vp), ("ld_aux", _i64),
                 ("p_drop", _f), ("seed", _u64), ("offset", _u64), ("split_k", C.c_int32), ("bias_grad", _vp), ("ws", _vp), ("ws_bytes", _i64), ("force_tile", C.c_int32),
-                ("defer_reduce", C.c_int32), ("split_k_used", C.c_int32)]
+                ("defer_reduce", C.c_int32), ("split_k_used", C.c_int32), ("ln", C.POINTER(LnFuse))]
 
 
 EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_DROPOUT_RES, EPI_DGELU, EPI_BIAS_GELU_GRAD, EPI_MUL_AUX = range(7)

@@ -550,14 +550,12 @@ class EncoderLayerFn(Function):
             ctxv, lse2, keep, ctx_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0], want_residual=True)
         else:
             (ctxv, lse2, keep), ctx_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0]), None
-        z1 = ops.gemm(ctxv, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x, p_drop=p_hid,
-                      seed=seeds[1][0], offset=seeds[1][1])
-        a, mean1, rstd1 = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
+        z1, a, mean1, rstd1 = ops.gemm_ln(ctxv, _w(so.dense.weight), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon,
+                                          epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x, p_drop=p_hid, seed=seeds[1][0], offset=seeds[1][1])
         pre = torch.empty((x.shape[0], inter.dense.weight.shape[0]), dtype=BF16, device=x.device)
         h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=inter.dense.bias, aux_out=pre)     # pre := gelu'(a W1^T + b1)
-        z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a, p_drop=p_hid,
-                      seed=seeds[2][0], offset=seeds[2][1])
-        y, mean2, rstd2 = ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)
+        z2, y, mean2, rstd2 = ops.gemm_ln(h, _w(out.dense.weight), out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon,
+                                          epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a, p_drop=p_hid, seed=seeds[2][0], offset=seeds[2][1])
         ctx.save_for_backward(x, qkv, ctxv, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, allow, ctx_lo)
         return y
 

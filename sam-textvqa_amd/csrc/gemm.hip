@@ -318,6 +318,85 @@ int pick_epilogue_split(int M, int N, int K, int64_t ws_bytes) {
   return s < 2 ? 1 : (int)s;
 }
 
+// The same pass for SAM_EPI_BIAS_DROPOUT_RES followed by a LayerNorm over the output row (sam_ln_fuse): one wave per row sums the partials, applies bias /
+// dropout / residual exactly as splitk_epilogue_kernel does, stores the bf16 sums (the backward's z) and normalises the ROUNDED values with the arithmetic of
+// ln_fwd_kernel (rowops.hip) -- bit-identical to the two launches it replaces.
+struct LnFuseArgs { const float* gamma; const float* beta; float eps; bf16_t* y; int64_t ldy; float* mean; float* rstd; };
+template <int NCH>
+__global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(const float* ws, int S, GemmArgs p, LnFuseArgs ln) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.M) return;
+  const int D = p.N, nchunk = D >> 2;
+  const int64_t MN = (int64_t)p.M * p.N;
+  unsigned seed_lo = p.seed_lo, seed_hi = p.seed_hi, off_lo = p.off_lo, off_hi = p.off_hi;
+  rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  float v[NCH][4];
+  float4 acc[NCH];
+  uint2 res[NCH];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {          // every load up front, at a clamped chunk
+    const int c = min(lane + 64 * j, nchunk - 1);
+    acc[j] = *reinterpret_cast<const float4*>(ws + (int64_t)row * D + 4 * c);
+    res[j] = p.residual ? *reinterpret_cast<const uint2*>(p.residual + (int64_t)row * p.ldr + 4 * c) : make_uint2(0u, 0u);
+  }
+  for (int s = 1; s < S; ++s)
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = min(lane + 64 * j, nchunk - 1);
+      const float4 b = *reinterpret_cast<const float4*>(ws + (int64_t)s * MN + (int64_t)row * D + 4 * c);
+      acc[j].x += b.x; acc[j].y += b.y; acc[j].z += b.z; acc[j].w += b.w;
+    }
+  float g4[NCH][4], b4[NCH][4];
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = min(lane + 64 * j, nchunk - 1), n = 4 * c;
+    v[j][0] = acc[j].x; v[j][1] = acc[j].y; v[j][2] = acc[j].z; v[j][3] = acc[j].w;
+    if (p.bias) {
+      const float4 bb = *reinterpret_cast<const float4*>(p.bias + n);
+      v[j][0] += bb.x; v[j][1] += bb.y; v[j][2] += bb.z; v[j][3] += bb.w;
+    }
+    if (p.thr16) {
+      const u32x4 rn = hidden_dropout_bits((unsigned)row, (unsigned)(n >> 3), off_lo, off_hi, seed_lo, seed_hi);
+      const unsigned lo = (n & 4) ? rn.z : rn.x, hi = (n & 4) ? rn.w : rn.y;
+      v[j][0] = (lo & 0xffffu) >= p.thr16 ? v[j][0] * p.inv_keep : 0.f;
+      v[j][1] = (lo >> 16) >= p.thr16 ? v[j][1] * p.inv_keep : 0.f;
+      v[j][2] = (hi & 0xffffu) >= p.thr16 ? v[j][2] * p.inv_keep : 0.f;
+      v[j][3] = (hi >> 16) >= p.thr16 ? v[j][3] * p.inv_keep : 0.f;
+    }
+    v[j][0] += bf_lo(res[j].x); v[j][1] += bf_hi(res[j].x); v[j][2] += bf_lo(res[j].y); v[j][3] += bf_hi(res[j].y);
+    const uint2 z = make_uint2(pack_bf16x2(v[j][0], v[j][1]), pack_bf16x2(v[j][2], v[j][3]));
+    if (lane + 64 * j < nchunk) *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (int64_t)row * p.ldc + n) = z;
+    v[j][0] = bf_lo(z.x); v[j][1] = bf_hi(z.x); v[j][2] = bf_lo(z.y); v[j][3] = bf_hi(z.y);      // LayerNorm sees what it would read back
+    *reinterpret_cast<float4*>(g4[j]) = *reinterpret_cast<const float4*>(ln.gamma + n);
+    *reinterpret_cast<float4*>(b4[j]) = *reinterpret_cast<const float4*>(ln.beta + n);
+  }
+  float sm = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    if (lane + 64 * j >= nchunk) v[j][0] = v[j][1] = v[j][2] = v[j][3] = 0.f;
+    sm += (v[j][0] + v[j][1]) + (v[j][2] + v[j][3]);
+  }
+  const float mean = wave_sum(sm) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NCH; ++j)
+    if (lane + 64 * j < nchunk)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { const float d_ = v[j][e] - mean; q += d_ * d_; }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / D + ln.eps);
+#pragma unroll
+  for (int j = 0; j < NCH; ++j) {
+    const int c = lane + 64 * j;
+    if (c < nchunk) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = g4[j][e] * ((v[j][e] - mean) * rstd) + b4[j][e];
+      *reinterpret_cast<uint2*>(ln.y + (int64_t)row * ln.ldy + 4 * c) = make_uint2(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]));
+    }
+  }
+  if (lane == 0) { ln.mean[row] = mean; ln.rstd[row] = rstd; }
+}
+
 template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
 int launch_cfg(GemmArgs a, hipStream_t st) {
   constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
@@ -488,6 +567,7 @@ extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N
 
 extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   SAM_REQUIRE(d, "sam_gemm_bf16: null descriptor");
+  if (d->ln) d->ln->done = 0;
   SAM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sam_gemm_bf16: empty problem %dx%dx%d", d->M, d->N, d->K);
   SAM_REQUIRE(d->A && d->B && d->C, "sam_gemm_bf16: null operand");
   SAM_REQUIRE(d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "sam_gemm_bf16: N, lda, ldb must be multiples of 8 (N=%d lda=%lld ldb=%lld)", d->N, (long long)d->lda, (long long)d->ldb);
@@ -538,9 +618,24 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
              : lay2 == 2 ? launch_cfg<64, 64, 2, 2, true, false, SAM_EPI_NONE, float>(g, st)
              : lay2 == 0 ? launch_cfg<64, 64, 2, 2, false, false, SAM_EPI_NONE, float>(g, st) : SAM_ERR_UNSUPPORTED;
       if (rc) { if (rc == SAM_ERR_UNSUPPORTED) sam_set_error("sam_gemm_bf16: no split kernel for layout (0,1)"); return rc; }
+      const int e2 = d->epilogue;
+      if (d->ln && e2 == SAM_EPI_BIAS_DROPOUT_RES && !d->c_is_f32 && d->N % 4 == 0 && d->N <= 2048) {
+        const sam_ln_fuse* l = d->ln;
+        SAM_REQUIRE(l->gamma && l->beta && l->y && l->mean && l->rstd && l->ldy >= d->N, "sam_gemm_bf16: incomplete sam_ln_fuse");
+        LnFuseArgs la = {l->gamma, l->beta, l->eps, (bf16_t*)l->y, l->ldy, l->mean, l->rstd};
+        const dim3 lgrid((unsigned)((d->M + 3) / 4));
+        switch ((d->N / 4 + 63) / 64) {
+#define SAM_LN_CASE(NC) case NC: splitk_epilogue_ln_kernel<NC><<<lgrid, dim3(256), 0, st>>>(d->ws, S, a, la); break;
+          SAM_LN_CASE(1) SAM_LN_CASE(2) SAM_LN_CASE(3) SAM_LN_CASE(4) SAM_LN_CASE(5) SAM_LN_CASE(6) SAM_LN_CASE(7) SAM_LN_CASE(8)
+#undef SAM_LN_CASE
+        }
+        SAM_LAUNCH_CHECK();
+        d->ln->done = 1;
+        *const_cast<int32_t*>(&d->split_k_used) = S;
+        return SAM_OK;
+      }
       const int64_t mn4 = (int64_t)d->M * d->N / 4;
       const dim3 grid((unsigned)min((int64_t)2048, (mn4 + 255) / 256));
-      const int e2 = d->epilogue;
 #define SAM_SPLIT_EPI(E, T) splitk_epilogue_kernel<E, T><<<grid, dim3(256), 0, st>>>(d->ws, S, a)
       if (d->c_is_f32) {
         if (e2 == SAM_EPI_NONE) SAM_SPLIT_EPI(SAM_EPI_NONE, float);

@@ -55,6 +55,7 @@ struct GemmOpt {
   float p_drop = 0.f;
   int64_t seed = 0, offset = 0;
   bool out_f32 = false;
+  sam_ln_fuse* ln = nullptr;       // gemm_ln: LayerNorm behind a BIAS_DROPOUT_RES epilogue, fused into the split-K reduction pass when there is one
 };
 
 Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOpt& o) {
@@ -70,6 +71,7 @@ Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOp
   if (o.aux_out) { d.aux_out = o.aux_out->data_ptr(); d.ld_aux = o.aux_out->stride(0); }
   if (o.aux_in) { d.aux_in = o.aux_in->data_ptr(); d.ld_aux = o.aux_in->stride(0); }
   d.p_drop = o.p_drop; d.seed = (uint64_t)o.seed; d.offset = (uint64_t)o.offset;
+  d.ln = o.ln;
   Tensor ws;
   if (M <= 4096 && K >= 1536 && M * N <= (4 << 20)) {   // skinny problem with a long K (TextBert's 20 tokens/sample): the library may split K
     d.split_k = -1;                                      // and fold the epilogue into the partial-sum reduction
@@ -79,6 +81,24 @@ Tensor gemm(const Tensor& a, const Tensor& b, bool a_kc, bool b_kc, const GemmOp
   }
   ok(sam_gemm_bf16(&d, cur_stream()), "sam_gemm_bf16");
   return out;
+}
+
+std::tuple<Tensor, Tensor, Tensor> ln_fwd(const Tensor& x, const Tensor& gamma, const Tensor& beta, double eps);
+// LayerNorm(gemm(...)) -> (z, y, mean, rstd): mirror of ops.gemm_ln (sam_ln_fuse when the library splits K, sam_layernorm_fwd otherwise: same bits)
+std::tuple<Tensor, Tensor, Tensor, Tensor> gemm_ln(const Tensor& a, const Tensor& b, const Tensor& gamma, const Tensor& beta, double eps, GemmOpt o) {
+  const int64_t M = a.size(0), N = b.size(0);
+  if (N % 4 || N > 2048 || gamma.scalar_type() != at::kFloat || beta.scalar_type() != at::kFloat) {
+    Tensor z = gemm(a, b, true, true, o);
+    auto [y, mean, rstd] = ln_fwd(z, gamma, beta, eps);
+    return {z, y, mean, rstd};
+  }
+  Tensor y = at::empty({M, N}, a.options()), mean = at::empty({M}, a.options().dtype(at::kFloat)), rstd = at::empty({M}, a.options().dtype(at::kFloat));
+  sam_ln_fuse ln = {(const float*)gamma.data_ptr(), (const float*)beta.data_ptr(), (float)eps, y.data_ptr(), y.stride(0), (float*)mean.data_ptr(), (float*)rstd.data_ptr(), 0};
+  o.ln = &ln;
+  Tensor z = gemm(a, b, true, true, o);
+  if (ln.done) return {z, y, mean, rstd};
+  auto [y2, mean2, rstd2] = ln_fwd(z, gamma, beta, eps);
+  return {z, y2, mean2, rstd2};
 }
 
 // dW += dy^T x (and db += colsum(dy)) for up to 8 jobs in one launch
@@ -413,14 +433,12 @@ std::vector<Tensor> encoder_layer_fwd(const Tensor& x, const Tensor& allow, at::
   if (fused_attn_bwd_enabled(x.size(0) / batch)) std::tie(ctx, lse2, keep, ctx_lo) = attn_fwd_train(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]);      // :563-598
   else { std::tie(ctx, lse2, keep) = attn_fwd(qkv, allow, batch, heads, scale, p_attn, seeds[0], seeds[1]); ctx_lo = at::empty({0}, x.options()); }
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_BO]; o.residual = &x; o.p_drop = (float)p_hid; o.seed = seeds[2]; o.offset = seeds[3];
-  Tensor z1 = gemm(ctx, params[P_WO], true, true, o);                                                     // BertSelfOutput via :653
-  auto [a, mean1, rstd1] = ln_fwd(z1, params[P_LN1W], params[P_LN1B], eps1);
+  auto [z1, a, mean1, rstd1] = gemm_ln(ctx, params[P_WO], params[P_LN1W], params[P_LN1B], eps1, o);      // BertSelfOutput via :653
   Tensor pre = at::empty({x.size(0), params[P_W1].size(0)}, x.options());
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_GELU_GRAD; o.bias = &params[P_B1]; o.aux_out = &pre;      // pre := gelu'(a W1^T + b1): the backward multiplies, no erf there
   Tensor h = gemm(a, params[P_W1], true, true, o);                                                        // BertIntermediate via :678
   o = GemmOpt(); o.epilogue = SAM_EPI_BIAS_DROPOUT_RES; o.bias = &params[P_B2]; o.residual = &a; o.p_drop = (float)p_hid; o.seed = seeds[4]; o.offset = seeds[5];
-  Tensor z2 = gemm(h, params[P_W2], true, true, o);                                                       // BertOutput via :680
-  auto [y, mean2, rstd2] = ln_fwd(z2, params[P_LN2W], params[P_LN2B], eps2);
+  auto [z2, y, mean2, rstd2] = gemm_ln(h, params[P_W2], params[P_LN2W], params[P_LN2B], eps2, o);          // BertOutput via :680
   return {y, x, qkv, ctx, lse2, keep, z1, mean1, rstd1, a, pre, h, z2, mean2, rstd2, ctx_lo};
 }
 

@@ -264,11 +264,12 @@ class _FusedLayer(_HipModule):
 def _layer_tail(layer, ctx, x):
     """everything of an encoder layer after the attention core, eval mode (no dropout), on a row subset: O-proj + LN, FFN + LN"""
     so, inter, out = layer.attention.output, layer.intermediate, layer.output
-    z1 = ops.gemm(ctx, _w(so.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x)
-    a, _, _ = ops.layernorm_fwd(z1, so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon)
+    # (gemm_ln: the LayerNorm rides on the GEMM's split-K reduction pass when there is one -- the few-row steps of the decoding loops -- and is its own launch otherwise)
+    _, a, _, _ = ops.gemm_ln(ctx, _w(so.dense.weight), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon,
+                             epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x)
     h = ops.gemm(a, _w(inter.dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=inter.dense.bias)      # (the 8-wave kernels carry this form; no aux_out: the derivative is not stored)
-    z2 = ops.gemm(h, _w(out.dense.weight), epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a)
-    return ops.layernorm_fwd(z2, out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon)[0]
+    return ops.gemm_ln(h, _w(out.dense.weight), out.LayerNorm.weight, out.LayerNorm.bias, out.LayerNorm.variance_epsilon,
+                       epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=out.dense.bias, residual=a)[1]
 
 
 def layer_infer_full(layer, x, allow, batch):

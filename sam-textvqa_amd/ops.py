@@ -251,7 +251,7 @@ def _dp(t):
 
 
 def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=None, out_dtype=BF16, epilogue=capi.EPI_NONE,
-         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0, split_k=0, bias_grad=None, force_tile=0):
+         bias=None, residual=None, aux_out=None, aux_in=None, accumulate=False, p_drop=0.0, seed=0, offset=0, split_k=0, bias_grad=None, force_tile=0, ln=None):
     """C[M,N] = epilogue(sum_k A(m,k) B(k,n)); see include/sam_hip.h `sam_gemm_bf16` for layouts and epilogues.
     a, b: 2-D bf16 tensors whose LAST dim is contiguous (row stride = leading dimension)."""
     for t, nm in ((a, "A"), (b, "B")):
@@ -278,6 +278,9 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
         split_k = -1       # skinny problem with a long K (TextBert's 20 tokens/sample, classifier dgrad): let the library split K and fold
                            # the epilogue into the partial-sum reduction (it declines when the grid already fills the chip)
     d.split_k, d.bias_grad, d.force_tile = int(split_k), _dp(bias_grad), int(force_tile)
+    if ln is not None:          # capi.LnFuse, filled by gemm_ln: the library normalises the rows itself when it runs this GEMM split over K
+        import ctypes as C
+        d.ln = C.pointer(ln)
     if split_k not in (0, 1):
         want = split_k if split_k > 0 else (32 if wgrad_split else 8)
         ws = _workspace(min(want * (M * N + M) * 4, 96 << 20), a.device, "splitk")
@@ -288,6 +291,26 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
         capi.call("sam_gemm_splitk_reduce", d.ws, d.split_k_used, M, N, out.data_ptr(), out.stride(0), d.bias_grad, capi.stream_handle(),
                   meta=dict(kernel="splitk_reduce", bytes=4.0 * M * N * (d.split_k_used + 2)))
     return out
+
+
+def gemm_ln(a, b, gamma, beta, eps, **kw):
+    """LayerNorm(gemm(a, b, epilogue=EPI_BIAS_DROPOUT_RES, ...)) -> (z, y, mean, rstd): z = the pre-LayerNorm sums (bf16, what the backward reads), y / mean /
+    rstd as layernorm_fwd(z).  One launch less when the GEMM runs split over K (sam_ln_fuse: the reduction pass normalises the rows it owns); the
+    separate sam_layernorm_fwd otherwise -- the same bits either way."""
+    m = a.shape[0] if kw.get("a_kcontig", True) else a.shape[1]
+    n = b.shape[0] if kw.get("b_kcontig", True) else b.shape[1]
+    if capi.profiler is not None or n % 4 or n > 2048 or gamma.dtype != torch.float32 or beta.dtype != torch.float32:
+        z = gemm(a, b, **kw)
+        return (z,) + tuple(layernorm_fwd(z, gamma, beta, eps))
+    y = torch.empty((m, n), dtype=BF16, device=a.device)
+    mean = torch.empty((m,), dtype=torch.float32, device=a.device)
+    rstd = torch.empty((m,), dtype=torch.float32, device=a.device)
+    ln = capi.LnFuse()
+    ln.gamma, ln.beta, ln.eps, ln.y, ln.ldy, ln.mean, ln.rstd, ln.done = gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), 0
+    z = gemm(a, b, ln=ln, **kw)
+    if ln.done:
+        return z, y, mean, rstd
+    return (z,) + tuple(layernorm_fwd(z, gamma, beta, eps))
 
 
 # ----------------------------------------------------------------------------- scratch

@@ -363,3 +363,32 @@ def test_c_abi_from_a_plain_cxx_host_program(tmp_path):
     exe = build_host_smoke(tmp_path)
     r = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_OK" in r.stdout, r.stdout[-3000:]
+
+
+def test_layernorm_inside_the_splitk_reduction_is_bit_identical_to_two_launches():
+    """sam_ln_fuse: LayerNorm(dropout(x W^T + b) + residual) (BertSelfOutput / BertOutput, sa_m4c.py:653,680,1016-1028).  When the library splits K (skinny M,
+    long K: TextBert's 1280 rows, the 320 / 64 rows of a decoding step) the pass that sums the partials normalises the rows it owns: z, y, mean, rstd must be
+    the bits of gemm + layernorm_fwd; when it does not split, `done` stays 0 and gemm_ln runs the separate LayerNorm"""
+    import torch
+    from sam_textvqa_amd import _capi as capi, ops
+    g = torch.Generator().manual_seed(12)
+    for (m, n, k, p_drop, expect_fused) in ((1280, 768, 3072, 0.1, True), (320, 768, 3072, 0.0, True), (64, 768, 3072, 0.1, True), (1283, 512, 2304, 0.1, True),
+                                           (1280, 768, 768, 0.1, False), (11648, 768, 3072, 0.1, False)):
+        a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).cuda()
+        w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).cuda()
+        bias = torch.randn(n, generator=g).cuda()
+        res = torch.randn(m, n, generator=g).to(torch.bfloat16).cuda()
+        gamma, beta = (1 + 0.1 * torch.randn(n, generator=g)).cuda(), (0.1 * torch.randn(n, generator=g)).cuda()
+        kw = dict(epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bias, residual=res, p_drop=p_drop, seed=7, offset=3)
+        z0 = ops.gemm(a, w, **kw)
+        y0, mean0, rstd0 = ops.layernorm_fwd(z0, gamma, beta, 1e-12)
+        ln = capi.LnFuse()
+        y = torch.empty_like(z0); mean = torch.empty(m, device="cuda"); rstd = torch.empty(m, device="cuda")
+        ln.gamma, ln.beta, ln.eps, ln.y, ln.ldy, ln.mean, ln.rstd, ln.done = gamma.data_ptr(), beta.data_ptr(), 1e-12, y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), 5
+        z1 = ops.gemm(a, w, ln=ln, **kw)
+        assert bool(ln.done) == expect_fused, (m, n, k, ln.done)
+        assert torch.equal(z0, z1)
+        if ln.done:
+            assert torch.equal(y, y0) and torch.equal(mean, mean0) and torch.equal(rstd, rstd0), (m, n, k)
+        z2, y2, mean2, rstd2 = ops.gemm_ln(a, w, gamma, beta, 1e-12, **kw)
+        assert torch.equal(z2, z0) and torch.equal(y2, y0) and torch.equal(mean2, mean0) and torch.equal(rstd2, rstd0)
