@@ -458,6 +458,7 @@ class DeferredWgrads:
     Their data-parallel regions are reported done after that launch, in backward order."""
     jobs, layers, acc = [], [], None
     late_stream, late = None, []
+    late_armed = False          # set by whoever will call join() before it reads the gradients (Trainer._eager_step); plain autograd use never leaves the issuing stream
 
     @classmethod
     def add(cls, layer, jobs, acc):
@@ -479,7 +480,7 @@ class DeferredWgrads:
             return
         jobs, layers, acc = cls.jobs, cls.layers, cls.acc
         cls.jobs, cls.layers, cls.acc = [], [], None
-        if late and jobs[0][0].is_cuda and wgrad_late_enabled():
+        if late and cls.late_armed and jobs[0][0].is_cuda and wgrad_late_enabled():
             # the group that closes the MMT's backward (its first layers): nothing on the rest of the backward path reads these weight gradients, and what
             # follows on the issuing stream is the tail's chain of small kernels (embedding blocks, object / OCR encoders, TextBert's 1280-row layers).
             # The ~0.3 ms launch runs on a stream of its own next to that chain instead of in front of it; Trainer joins it before the gradient norm.
@@ -511,6 +512,11 @@ class DeferredWgrads:
     @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
+        if cls.late:                 # a launch may still be reading its operands on the late stream: the issuing stream waits before they are dropped
+            try:
+                torch.cuda.current_stream().wait_stream(cls.late_stream)
+            except RuntimeError:
+                pass
         cls.late = []
 
 

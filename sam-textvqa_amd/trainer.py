@@ -321,6 +321,7 @@ class Trainer:
         defer_ln = self.defer_ln
         if defer_ln:
             self._set_ln_defer(True)
+        DeferredWgrads.late_armed = True                        # (this method joins the late stream below, before anything reads a gradient)
         try:
             if self._grad_one is None or self._grad_one.device != loss.device:
                 self._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
@@ -333,6 +334,7 @@ class Trainer:
             parallel.active_reducer = None
             raise
         finally:
+            DeferredWgrads.late_armed = False
             if defer_ln:
                 self._set_ln_defer(False)
         side = getattr(model, "_side_stream", None)
