@@ -340,6 +340,11 @@ int sam_greedy_pick(const float* fixed_scores, int64_t ld_fixed, const float* oc
                     void* stream);
 int sam_beam_step(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,
                   int32_t* ctl, float* cum, uint8_t* done, int64_t* seqs, int64_t* prev_pos, void* stream);
+/* the same step as two launches -- the candidate scan over one block per (sample, beam) instead of one per sample, then a merge of the K lists per sample:
+ * identical results (same candidates, same order, same tie rule), a quarter of the time at beam 5.  ws: sam_beam_step_ws_bytes(B, K) bytes of scratch. */
+int64_t sam_beam_step_ws_bytes(int B, int K);
+int sam_beam_step_split(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,
+                        int32_t* ctl, float* cum, uint8_t* done, int64_t* seqs, int64_t* prev_pos, void* ws, void* stream);
 
 /* ---- greedy decoding steps t_begin .. t_end-1 as ONE persistent launch (csrc/decode_steps.hip; sam/sa_m4c.py:285-302, rows of 294-302's loop) ----
  * After a full first pass (step 0) every later step only has ONE new row per sample: decoder row t, whose input token was picked by step t-1 and

@@ -173,7 +173,145 @@ __global__ __launch_bounds__(NT) void beam_step_kernel(const float* __restrict__
   }
 }
 
+// ---- the same step as two launches: the candidate scan -- K * (V + No) log-sigmoids per sample, the step's whole cost -- spread over one block per
+// (sample, beam) instead of one per sample (64 blocks of four waves on 256 CUs: 76 us per step at beam 5), then a merge of the K lists per sample.
+// ws: [B][K][KMAXW] (value, flat index) pairs, written by the scan, read by the merge.
+constexpr int KMAXW = 16;
+template <int KMAX>
+__global__ __launch_bounds__(NT) void beam_scan_kernel(const float* __restrict__ fixed, int64_t ldf, const float* __restrict__ ocr, int64_t ldo, int V, int No, int S, int K,
+                                                       int eos, int t_by_value, const int* __restrict__ ctl, const float* __restrict__ cum,
+                                                       const unsigned char* __restrict__ done, Best* __restrict__ ws) {
+  __shared__ Best red[NT / 64];
+  const int b = blockIdx.x / K, j = blockIdx.x % K, tid = threadIdx.x, Vt = V + No;
+  const int t = ctl ? ctl[0] : t_by_value;
+  if (ctl && ctl[1]) return;
+  Best* out = ws + (int64_t)blockIdx.x * KMAXW;
+  const float cj = cum[b * K + j];
+  if (t == 0 && j > 0) {                           // only beam 0 is live at the first step
+    if (tid < K) out[tid] = Best{-INFINITY, 0x7fffffff};
+    return;
+  }
+  if (done[b * K + j]) {                           // the single candidate of a completed beam
+    if (tid < K) out[tid] = tid == 0 ? Best{cj, j * Vt + eos} : Best{-INFINITY, 0x7fffffff};
+    return;
+  }
+  float lv[KMAX]; int li[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) { lv[q] = -INFINITY; li[q] = 0x7fffffff; }
+  float wv = -INFINITY; int wi = 0x7fffffff;
+  const int64_t row = (int64_t)(b * K + j) * S + t;
+  const float* f = fixed + row * ldf;
+  const float* o = ocr + row * ldo;
+  constexpr int UN = 8;
+  for (int c0 = tid; c0 < Vt; c0 += NT * UN) {
+    float xs[UN];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = min(c0 + u * NT, Vt - 1);
+      xs[u] = c < V ? f[c] : o[c - V];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int c = c0 + u * NT;
+      if (c >= Vt) break;
+      float v = logf(1.0f / (1.0f + expf(-xs[u]))) + cj;
+      int id = j * Vt + c;
+      if (v > wv || (v == wv && id < wi)) {
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q)
+          if (q < K && (v > lv[q] || (v == lv[q] && id < li[q]))) { const float tv = lv[q]; const int ti = li[q]; lv[q] = v; li[q] = id; v = tv; id = ti; }
+#pragma unroll
+        for (int q = 0; q < KMAX; ++q)
+          if (q == K - 1) { wv = lv[q]; wi = li[q]; }
+      }
+    }
+  }
+  for (int r = 0; r < K; ++r) {
+    const Best w = block_best(Best{lv[0], li[0]}, red);
+    if (w.i == li[0] && w.i != 0x7fffffff) {
+#pragma unroll
+      for (int q = 0; q + 1 < KMAX; ++q) { lv[q] = lv[q + 1]; li[q] = li[q + 1]; }
+      lv[KMAX - 1] = -INFINITY; li[KMAX - 1] = 0x7fffffff;
+    }
+    if (tid == 0) out[r] = w;
+  }
+}
+
+__global__ __launch_bounds__(NT) void beam_merge_kernel(const Best* __restrict__ ws, int Vt, int S, int K, int B, int eos, int t_by_value, int* __restrict__ ctl,
+                                                        float* __restrict__ cum, unsigned char* __restrict__ done, int64_t* __restrict__ seqs, int64_t* __restrict__ prev_pos) {
+  __shared__ Best red[NT / 64];
+  __shared__ float s_cum[KMAXW], s_val[KMAXW];
+  __shared__ int s_idx[KMAXW];
+  __shared__ int64_t s_seq[KMAXW * 64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int t = ctl ? ctl[0] : t_by_value;
+  if (ctl && ctl[1]) {
+    if (prev_pos && tid < K) prev_pos[b * K + tid] = b * K + tid;
+    return;
+  }
+  if (tid < K) s_cum[tid] = cum[b * K + tid];
+  for (int e = tid; e < K * S; e += NT) s_seq[e] = seqs[(int64_t)b * K * S + e];
+  // thread (j, r) holds candidate r of beam j's list (K * K <= 256 = NT)
+  Best mine = {-INFINITY, 0x7fffffff};
+  if (tid < K * K) mine = ws[((int64_t)b * K + tid / K) * KMAXW + tid % K];
+  for (int r = 0; r < K; ++r) {
+    const Best w = block_best(mine, red);
+    if (w.i == mine.i && w.i != 0x7fffffff) mine = Best{-INFINITY, 0x7fffffff};      // (flat indices are unique: exactly one owner)
+    if (tid == 0) { s_val[r] = w.v; s_idx[r] = w.i == 0x7fffffff ? 0 : w.i; }
+  }
+  __syncthreads();
+  for (int e = tid; e < K * S; e += NT) {
+    const int j = e / S, pos = e - j * S, src = s_idx[j] / Vt;
+    int64_t v = s_seq[src * S + pos];
+    if (pos == t + 1) v = s_idx[j] % Vt;
+    seqs[(int64_t)b * K * S + e] = v;
+  }
+  int ndone = 0;
+  if (tid < K) {
+    const int src = s_idx[tid] / Vt, tok = s_idx[tid] % Vt;
+    cum[b * K + tid] = s_cum[src] + s_val[tid];
+    const int d = (t + 1 < S) ? (tok == eos ? 1 : 0) : 1;
+    done[b * K + tid] = (unsigned char)d;
+    if (prev_pos) prev_pos[b * K + tid] = b * K + src;
+    ndone = d;
+  }
+  if (ctl) {
+    if (tid < 64) {
+      ndone = (int)wave_sum((float)ndone);
+      if (tid == 0) {
+        atomicAdd(ctl + 3, ndone);
+        __threadfence();
+        const int arrived = atomicAdd(ctl + 2, 1);
+        if (arrived == B - 1) {
+          const int total = atomicAdd(ctl + 3, 0);
+          ctl[0] = t + 1;
+          if (total == B * K || t + 1 >= S) ctl[1] = 1;
+          ctl[2] = 0; ctl[3] = 0;
+          __threadfence();
+        }
+      }
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int64_t sam_beam_step_ws_bytes(int B, int K) { return (int64_t)B * K * KMAXW * (int64_t)sizeof(Best); }
+
+extern "C" int sam_beam_step_split(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int B, int K, int S, int V, int No, int eos, int t,
+                                   int32_t* ctl, float* cum, uint8_t* done, int64_t* seqs, int64_t* prev_pos, void* ws, void* stream) {
+  SAM_REQUIRE(fixed_scores && ocr_scores && cum && done && seqs && ws, "sam_beam_step_split: null pointer");
+  SAM_REQUIRE(B > 0 && K >= 1 && K <= 16 && S >= 1 && S <= 64 && V > 0 && No >= 0, "sam_beam_step: need 1 <= beam size <= 16, 1 <= decoding steps <= 64");
+  SAM_REQUIRE(eos >= 0 && eos < V + No && (ctl || (t >= 0 && t < S)), "sam_beam_step: EOS index / step out of range");
+  hipStream_t st = (hipStream_t)stream;
+  Best* w = (Best*)ws;
+  if (K <= 4) beam_scan_kernel<4><<<dim3(B * K), dim3(NT), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, V, No, S, K, eos, t, ctl, cum, done, w);
+  else if (K <= 8) beam_scan_kernel<8><<<dim3(B * K), dim3(NT), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, V, No, S, K, eos, t, ctl, cum, done, w);
+  else beam_scan_kernel<16><<<dim3(B * K), dim3(NT), 0, st>>>(fixed_scores, ld_fixed, ocr_scores, ld_ocr, V, No, S, K, eos, t, ctl, cum, done, w);
+  beam_merge_kernel<<<dim3(B), dim3(NT), 0, st>>>(w, V + No, S, K, B, eos, t, ctl, cum, done, seqs, prev_pos);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
 
 extern "C" int sam_greedy_pick(const float* fixed_scores, int64_t ld_fixed, const float* ocr_scores, int64_t ld_ocr, int R, int S, int V, int No, int64_t* prev_inds,
                                void* stream) {

@@ -205,6 +205,12 @@ def beam_step(fixed, ocr, n_samples, beam, seqs, cum, done, eos, t=0, ctl=None, 
     """one BeamSearch.decode step (sam_beam_step), state (seqs int64 [B*K, S], cum f32 [B*K], done u8 [B*K]) updated in place"""
     _chk(seqs, torch.int64, "seqs"); _chk(cum, torch.float32, "cum"); _chk(done, torch.uint8, "done")
     s = seqs.shape[1]
+    if beam > 1 and os.environ.get("SAM_BEAM_STEP_SPLIT", "1") != "0":
+        # scan over one block per (sample, beam) + merge (sam_beam_step_split): the same result in a quarter of the time at beam 5
+        ws = _workspace(int(capi.call("sam_beam_step_ws_bytes", int(n_samples), int(beam))), fixed.device, "beam_step")
+        capi.call("sam_beam_step_split", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), int(n_samples), int(beam), s, fixed.shape[1], ocr.shape[1], int(eos),
+                  int(t), capi.ptr(ctl), capi.ptr(cum), capi.ptr(done), capi.ptr(seqs), capi.ptr(prev_pos), capi.ptr(ws), capi.stream_handle())
+        return
     capi.call("sam_beam_step", capi.ptr(fixed), fixed.stride(0), capi.ptr(ocr), ocr.stride(0), int(n_samples), int(beam), s, fixed.shape[1], ocr.shape[1], int(eos), int(t),
               capi.ptr(ctl), capi.ptr(cum), capi.ptr(done), capi.ptr(seqs), capi.ptr(prev_pos), capi.stream_handle())
 

@@ -95,6 +95,34 @@ def test_beam_step_random_scores_vs_oracle(beam, vocab, n_ocr):
     assert torch.equal(seqs.cpu(), bd["complete_seqs"].reshape(b * beam, s))
 
 
+@pytest.mark.parametrize("beam,vocab,n_ocr", [(2, 41, 7), (5, 5000, 50), (16, 300, 10)])
+def test_beam_step_as_scan_plus_merge_equals_the_single_kernel(beam, vocab, n_ocr, monkeypatch):
+    """sam_beam_step_split (candidate scan over one block per (sample, beam), then a merge per sample) and sam_beam_step: the same state after every step of a
+    whole search, bit for bit -- tokens, cumulative scores, completed flags, source rows, the device-side step counter and finished flag"""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(7 + beam)
+    b, s, eos = 9, 6, 2
+    scores = [torch.randn(b * beam * s, vocab + n_ocr, generator=g) * 1.5 for _ in range(s)]
+    for t in range(s):
+        scores[t][: 4 * beam * s, eos] += 5.0                  # some samples complete early
+        scores[t][-s:, 7] = scores[t][-s:, 9]                   # exact ties
+    states = {}
+    for split in ("0", "1"):
+        monkeypatch.setenv("SAM_BEAM_STEP_SPLIT", split)
+        seqs = torch.zeros(b * beam, s, dtype=torch.int64).cuda(); seqs[:, 0] = 1
+        cum = torch.zeros(b * beam).cuda(); done = torch.zeros(b * beam, dtype=torch.uint8).cuda()
+        ctl = torch.zeros(4, dtype=torch.int32).cuda(); pp = torch.zeros(b * beam, dtype=torch.int64).cuda()
+        trace = []
+        for t in range(s):
+            dev = scores[t].cuda()
+            ops.beam_step(dev[:, :vocab].contiguous(), dev[:, vocab:].contiguous(), b, beam, seqs, cum, done, eos, ctl=ctl, prev_pos=pp)
+            trace.append((seqs.cpu().clone(), cum.cpu().clone(), done.cpu().clone(), pp.cpu().clone(), ctl.cpu().clone()))
+        states[split] = trace
+    for ta, tb in zip(states["0"], states["1"]):
+        for x, y in zip(ta, tb):
+            assert torch.equal(x, y)
+
+
 def test_attn_fwd_dec_equals_the_full_kernel_on_decoder_rows():
     from sam_textvqa_amd import ops
     g = torch.Generator().manual_seed(5)
