@@ -27,6 +27,11 @@ struct RowArgs {
 };
 
 __device__ __forceinline__ float bf(unsigned short v) { return __uint_as_float((unsigned)v << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// acc + a.lo * b.lo + a.hi * b.hi on packed bf16 pairs (v_dot2c_f32_bf16): one instruction where unpack + two multiply-adds were four
+__device__ __forceinline__ float dot2_bf16(unsigned a, unsigned b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b), acc, false);
+}
 
 __global__ __launch_bounds__(NT) void attn_dec_row_kernel(RowArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -58,8 +63,16 @@ __global__ __launch_bounds__(NT) void attn_dec_row_kernel(RowArgs a) {
   for (int j = wave; j < a.group; j += NWV) {
     const int b = b0 * a.group + j;
     const bf16_t* dbase = a.qkv_dec + (int64_t)b * a.n_dec * ld + h * HD;
-    q_w[lane] = bf(dbase[(int64_t)a.t * ld + lane]);
+    // the query row as 32 packed pairs, in registers for the whole beam (lanes 0..31 fetch a dword each, everybody reads all of them back)
+    unsigned* q_u = reinterpret_cast<unsigned*>(q_w);
+    if (lane < HD / 2) q_u[lane] = reinterpret_cast<const unsigned*>(dbase + (int64_t)a.t * ld)[lane];
     __builtin_amdgcn_wave_barrier();
+    unsigned qp[HD / 2];
+#pragma unroll
+    for (int c = 0; c < HD / 8; ++c) {
+      const uint4 t4 = *reinterpret_cast<const uint4*>(q_u + 4 * c);
+      qp[4 * c] = t4.x; qp[4 * c + 1] = t4.y; qp[4 * c + 2] = t4.z; qp[4 * c + 3] = t4.w;
+    }
     // ---- scores: lane = key
     float sc[MAXKEYS / 64];
     float mx = -INFINITY;
@@ -72,20 +85,16 @@ __global__ __launch_bounds__(NT) void attn_dec_row_kernel(RowArgs a) {
       float acc = 0.f;
       if (key < a.n_enc) {
         const unsigned* kr = reinterpret_cast<const unsigned*>(Ks + key * KROW);
+        float a1 = 0.f;
 #pragma unroll
-        for (int d2 = 0; d2 < HD / 2; ++d2) {
-          const unsigned w = kr[d2];
-          acc = fmaf(q_w[2 * d2], __uint_as_float(w << 16), acc);
-          acc = fmaf(q_w[2 * d2 + 1], __uint_as_float(w & 0xffff0000u), acc);
-        }
+        for (int d2 = 0; d2 < HD / 2; d2 += 2) { acc = dot2_bf16(qp[d2], kr[d2], acc); a1 = dot2_bf16(qp[d2 + 1], kr[d2 + 1], a1); }
+        acc += a1;
       } else if (key < nkeys) {
         const unsigned* kr = reinterpret_cast<const unsigned*>(dbase + (int64_t)(key - a.n_enc) * ld + Dm);
+        float a1 = 0.f;
 #pragma unroll
-        for (int d2 = 0; d2 < HD / 2; ++d2) {
-          const unsigned w = kr[d2];
-          acc = fmaf(q_w[2 * d2], __uint_as_float(w << 16), acc);
-          acc = fmaf(q_w[2 * d2 + 1], __uint_as_float(w & 0xffff0000u), acc);
-        }
+        for (int d2 = 0; d2 < HD / 2; d2 += 2) { acc = dot2_bf16(qp[d2], kr[d2], acc); a1 = dot2_bf16(qp[d2 + 1], kr[d2 + 1], a1); }
+        acc += a1;
       }
       if (in) { sc[m] = acc * a.scale; mx = fmaxf(mx, sc[m]); }
     }
