@@ -65,14 +65,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, int64_t ldx,
       if (lane + 64 * j >= nchunk) v[i][j][0] = v[i][j][1] = v[i][j][2] = v[i][j][3] = 0.f;
       s += (v[i][j][0] + v[i][j][1]) + (v[i][j][2] + v[i][j][3]);
     }
-    const float mean = wave_sum(s) / D;
+    const float mean = wave_sum_v(s) / D;
     float q = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
       if (lane + 64 * j < nchunk)
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float d = v[i][j][e] - mean; q += d * d; }
-    const float rstd = 1.0f / sqrtf(wave_sum(q) / D + eps);
+    const float rstd = 1.0f / sqrtf(wave_sum_v(q) / D + eps);
     if (row >= M) continue;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -88,15 +88,46 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* x, int64_t ldx,
   }
 }
 
+// a 4-element chunk in its stored form (what a prefetched row keeps in registers until its turn: 2 registers per bf16 chunk instead of 4)
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+  typedef uint2 R;
+  static __device__ __forceinline__ R ld(const void* p, int64_t idx) { return *reinterpret_cast<const uint2*>(reinterpret_cast<const bf16_t*>(p) + idx); }
+  static __device__ __forceinline__ void expand(const R& x, float* v) { v[0] = bf_lo(x.x); v[1] = bf_hi(x.x); v[2] = bf_lo(x.y); v[3] = bf_hi(x.y); }
+};
+template <> struct Raw4<float> {
+  typedef float4 R;
+  static __device__ __forceinline__ R ld(const void* p, int64_t idx) { return *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + idx); }
+  static __device__ __forceinline__ void expand(const R& x, float* v) { v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+};
+
+// empty volatile asm statements that "touch" a value: the compiler keeps them in program order, so everything computed FROM the value stays behind
+// the statement and everything it was computed from in front of it (the LayerNorm backward uses them to keep one row's work in one piece)
+__device__ __forceinline__ void pin(unsigned& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(uint2& v) { pin(v.x); pin(v.y); }
+__device__ __forceinline__ void pin(float4& v) { pin(v.x); pin(v.y); pin(v.z); pin(v.w); }
+
 // ws layout: [LN_PARTIAL_BLOCKS][3][D]  (dgamma, dbeta, dbias partials)
-template <typename InT, int NCH>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
-                                                     const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16,
-                                                     float inv_keep, unsigned seed_lo, unsigned seed_hi, unsigned off_lo, unsigned off_hi, const unsigned long long* rng_state, float* ws) {
-  if (thr16) rng_resolve(rng_state, seed_lo, seed_hi, off_lo, off_hi);
-  constexpr int LN_ROWS = NCH <= 3 ? 3 : (NCH == 4 ? 2 : 1);  // rows a wave keeps in flight (VGPR budget: <= 256 for 2 waves/SIMD)
+// Wave w of block b takes rows b*4 + w, + 4*grid, + 8*grid, ... ONE AT A TIME, with the next NS - 1 rows of its sequence already requested (raw bf16 in
+// registers: a ring of NS slots, the loop unrolled NS times so that every slot is a fixed register set).  Round 4's first version took three rows per
+// trip -- loads, reductions, stores, then the next three loads: with 2048 waves for 11648 rows every wave of the chip was in the same phase at the
+// same time (a 19 MB read burst, then VALU with the memory system idle, then a store burst, twice over: 35 us for 72 MB in the step).  Here the
+// loads of rows r+1, r+2 are in flight while row r is reduced and stored, and the stores of row r while r+1 is reduced.
+// Row order per wave and the order of every addition are those of the first version: identical dx / dxd and identical partial sums.
+// FULL: D == 256 * NCH (every chunk of every lane is inside the row: no per-chunk bounds selects).
+// MODE: 0 = dx only, 1 = dx and an identical dxd (dropout off), 2 = dx and the dropout-masked dxd (compile-time: run-time tests of dxd / thr16 put six
+// uniform branches between the stores of every chunk).
+template <typename InT, int NCH, bool FULL, int MODE>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int64_t ldd, const void* __restrict__ x, int64_t ldx, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ gamma, int M, int D, bf16_t* __restrict__ dx,
+                                                     bf16_t* __restrict__ dxd, int64_t ldo, unsigned thr16, float inv_keep, unsigned seed_lo, unsigned seed_hi,
+                                                     unsigned off_lo, unsigned off_hi, const unsigned long long* rng_state, float* __restrict__ ws) {
+  if (MODE == 2) rng_resolve(rng_state, seed_lo, seed_hi, off_lo, off_hi);
+  constexpr int NS = NCH <= 3 ? 3 : (NCH == 4 ? 2 : 1);      // ring slots = rows a wave has requested or is working on (VGPR budget)
+  typedef typename Raw4<InT>::R XR;
   __shared__ float red[4][64 * 4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int nchunk = D >> 2;
   float ag[NCH][4], ab[NCH][4], ad[NCH][4];
 #pragma unroll
@@ -108,81 +139,107 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* dy, int64_t l
   for (int j = 0; j < NCH; ++j) {
     const int c = lane + 64 * j;
     Ld4<float>::ld(gamma, 4 * min(c, nchunk - 1), gm[j]);
-    if (c >= nchunk) gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
+    if (!FULL && c >= nchunk) gm[j][0] = gm[j][1] = gm[j][2] = gm[j][3] = 0.f;
   }
-  // LN_ROWS rows per wave in flight: all their loads are issued before the first reduction, so one wave keeps LN_ROWS x 3 KB
-  // outstanding (8 waves/CU x 9 KB covers the HBM latency-bandwidth product; one row at a time reached 1.8 TB/s)
+  __builtin_amdgcn_sched_barrier(0);        // gamma first: the first row needs it, and loads are waited for in issue order
+  const DropHalfConsts hk = dropout_half_consts((lane & 1) != 0);     // chunk c = lane + 64 j: (c & 1) == (lane & 1)
   const int rstride = gridDim.x * 4;
-  for (int row0 = blockIdx.x * 4 + wave; row0 < M; row0 += rstride * LN_ROWS) {
-    float xh[LN_ROWS][NCH][4], g[LN_ROWS][NCH][4], rs[LN_ROWS], s1[LN_ROWS], s2[LN_ROWS];
-    float xv[LN_ROWS][NCH][4], dv[LN_ROWS][NCH][4], mu[LN_ROWS];
-#pragma unroll
-    for (int i = 0; i < LN_ROWS; ++i) {
-      // every load is unconditional, at a clamped (row, chunk): a predicated load compiles to a branch + s_waitcnt vmcnt(0), which left
-      // ONE load pair in flight per wave (1.8 TB/s); dead rows / chunks are zeroed after the fact
-      const bool live = row0 + i * rstride < M;
-      const int row = min(row0 + i * rstride, M - 1);
-      mu[i] = mean[row];
-      rs[i] = live ? rstd[row] : 0.f;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = min(lane + 64 * j, nchunk - 1);
-        Ld4<InT>::ld(x, (int64_t)row * ldx + 4 * c, xv[i][j]);
-        Ld4<bf16_t>::ld(dy, (int64_t)row * ldd + 4 * c, dv[i][j]);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < LN_ROWS; ++i) {
-      const bool live = row0 + i * rstride < M;
-      float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = lane + 64 * j;
-        if (!live || c >= nchunk)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) xv[i][j][e] = dv[i][j][e] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          xh[i][j][e] = (live && c < nchunk) ? (xv[i][j][e] - mu[i]) * rs[i] : 0.f;
-          g[i][j][e] = dv[i][j][e] * gm[j][e];
-          t1 += g[i][j][e];
-          t2 += g[i][j][e] * xh[i][j][e];
-          ag[j][e] += dv[i][j][e] * xh[i][j][e];
-          ab[j][e] += dv[i][j][e];
-        }
-      }
-      s1[i] = t1; s2[i] = t2;
-    }
-#pragma unroll
-    for (int i = 0; i < LN_ROWS; ++i) { s1[i] = wave_sum(s1[i]) / D; s2[i] = wave_sum(s2[i]) / D; }
-#pragma unroll
-    for (int i = 0; i < LN_ROWS; ++i) {
-      const int row = row0 + i * rstride;
-      if (row >= M) continue;
-#pragma unroll
-      for (int j = 0; j < NCH; ++j) {
-        const int c = lane + 64 * j;
-        if (c >= nchunk) continue;
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = rs[i] * (g[i][j][e] - s1[i] - xh[i][j][e] * s2[i]);
-        st4_bf16(dx, (int64_t)row * ldo + 4 * c, o);
-        if (dxd) {
-          if (thr16) {  // same (row, col/8) Philox stream as the GEMM epilogue that produced the forward mask
-            const u32x4 rn = hidden_dropout_bits((unsigned)row, (unsigned)(c >> 1), off_lo, off_hi, seed_lo, seed_hi);
-            const unsigned lo = (c & 1) ? rn.z : rn.x, hi = (c & 1) ? rn.w : rn.y;
-            o[0] = (lo & 0xffffu) >= thr16 ? o[0] * inv_keep : 0.f;
-            o[1] = (lo >> 16) >= thr16 ? o[1] * inv_keep : 0.f;
-            o[2] = (hi & 0xffffu) >= thr16 ? o[2] * inv_keep : 0.f;
-            o[3] = (hi >> 16) >= thr16 ? o[3] * inv_keep : 0.f;
-          }
-          st4_bf16(dxd, (int64_t)row * ldo + 4 * c, o);
-        }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) ad[j][e] += o[e];
-      }
-    }
+  XR xr[NS][NCH];
+  uint2 dr[NS][NCH];
+  float mu[NS], rs[NS];
+  // every load is unconditional, at a clamped (row, chunk): a predicated load compiles to a branch + s_waitcnt vmcnt(0)
+#define LN_BWD_REQUEST(S, ROW)                                                                     \
+  do {                                                                                             \
+    const int row_ = min((ROW), M - 1);                                                            \
+    mu[S] = mean[row_]; rs[S] = rstd[row_];                                                        \
+    _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                              \
+      const int c_ = FULL ? lane + 64 * j : min(lane + 64 * j, nchunk - 1);                        \
+      xr[S][j] = Raw4<InT>::ld(x, (int64_t)row_ * ldx + 4 * c_);                                   \
+      dr[S][j] = Raw4<bf16_t>::ld(dy, (int64_t)row_ * ldd + 4 * c_);                               \
+    }                                                                                              \
+  } while (0)
+  // One slot's turn: reduce and store the row it holds, request the row NS places further on.  The main loop runs the trips in which EVERY slot of EVERY
+  // wave holds a live row (a uniform count, no test inside: the compiler's s_waitcnt placement merges the pending-load state of joining paths to the
+  // more conservative one, and a skipped slot re-joining the loop -- or leaving it: the loop exits are unified into flags and joins -- turned every wait
+  // into a wait for nearly all outstanding loads); the ragged rest, at most NS rows per wave and already requested by the last trip, follows behind it.
+  // The first trip is peeled so that the loop header joins two identical end-of-trip states.
+#define LN_BWD_SLOT(S, ROW, REQ)                                                                                                     \
+  {                                                                                                                                \
+    const int row = (ROW);                                                                                                         \
+    float xh[NCH][4], g[NCH][4];                                                                                                   \
+    float t1 = 0.f, t2 = 0.f;                                                                                                      \
+    asm volatile("" ::: "memory");                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < NCH; ++j) { pin(xr[S][j]); pin(dr[S][j]); }     /* this row's arithmetic starts here, not earlier */ \
+    _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                                                              \
+      const int c = lane + 64 * j;                                                                                                 \
+      float xv[4], dv[4];                                                                                                          \
+      Raw4<InT>::expand(xr[S][j], xv);                                                                                             \
+      Raw4<bf16_t>::expand(dr[S][j], dv);                                                                                          \
+      if (!FULL && c >= nchunk) { _Pragma("unroll") for (int e = 0; e < 4; ++e) xv[e] = dv[e] = 0.f; }                             \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                                              \
+        xh[j][e] = (FULL || c < nchunk) ? (xv[e] - mu[S]) * rs[S] : 0.f;                                                           \
+        g[j][e] = dv[e] * gm[j][e];                                                                                                \
+        t1 += g[j][e];                                                                                                             \
+        t2 += g[j][e] * xh[j][e];                                                                                                  \
+        ag[j][e] += dv[e] * xh[j][e];                                                                                              \
+        ab[j][e] += dv[e];                                                                                                         \
+      }                                                                                                                            \
+    }                                                                                                                              \
+    const float rsv = rs[S];                                                                                                       \
+    pin(t1); pin(t2);                                                                                                              \
+    if (REQ) {                                    /* this slot's next row: its registers are free from here on (pinned: left alone, the */ \
+      asm volatile("" ::: "memory");              /* scheduler sinks these loads behind the other slots' arithmetic)                    */ \
+      __builtin_amdgcn_sched_barrier(0);                                                                                           \
+      LN_BWD_REQUEST(S, row + NS * rstride);                                                                                       \
+      __builtin_amdgcn_sched_barrier(0);                                                                                           \
+      asm volatile("" ::: "memory");                                                                                               \
+    }                                                                                                                              \
+    const float s1 = wave_sum_v(t1) / D, s2 = wave_sum_v(t2) / D;                                                                      \
+    const unsigned rkey = MODE == 2 ? hidden_dropout_row_key((unsigned)row, off_lo, off_hi, seed_lo, seed_hi) : 0u;                \
+    _Pragma("unroll") for (int j = 0; j < NCH; ++j) {                                                                              \
+      const int c = lane + 64 * j;                                                                                                 \
+      if (!FULL && c >= nchunk) continue;                                                                                          \
+      float o[4];                                                                                                                  \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) o[e] = rsv * (g[j][e] - s1 - xh[j][e] * s2);                                   \
+      st4_bf16(dx, (int64_t)row * ldo + 4 * c, o);                                                                                 \
+      if (MODE >= 1) {                                                                                                             \
+        if (MODE == 2) { /* the (row, col/8) stream of the GEMM epilogue that drew the forward mask; this lane's four columns = half a draw */ \
+          unsigned lo, hi;                                                                                                         \
+          dropout_bits_half(rkey, (unsigned)(c >> 1), hk, lo, hi);                                                                 \
+          o[0] = (lo & 0xffffu) >= thr16 ? o[0] * inv_keep : 0.f;                                                                  \
+          o[1] = (lo >> 16) >= thr16 ? o[1] * inv_keep : 0.f;                                                                      \
+          o[2] = (hi & 0xffffu) >= thr16 ? o[2] * inv_keep : 0.f;                                                                  \
+          o[3] = (hi >> 16) >= thr16 ? o[3] * inv_keep : 0.f;                                                                      \
+        }                                                                                                                          \
+        st4_bf16(dxd, (int64_t)row * ldo + 4 * c, o);                                                                              \
+      }                                                                                                                            \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) ad[j][e] += o[e];                                                              \
+    }                                                                                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                                                                             \
   }
+#define LN_BWD_TRIP(R0)                                                  \
+  LN_BWD_SLOT(0, (R0), true)                                             \
+  if constexpr (NS > 1) LN_BWD_SLOT(1, (R0) + rstride, true)             \
+  if constexpr (NS > 2) LN_BWD_SLOT(2, (R0) + 2 * rstride, true)
+  const int row00 = blockIdx.x * 4 + wave;
+  // requests in slot order (sched_barrier: the scheduler would interleave them, and loads return -- and are waited for -- in issue order)
+  LN_BWD_REQUEST(0, row00);
+  __builtin_amdgcn_sched_barrier(0);
+  if constexpr (NS > 1) { LN_BWD_REQUEST(1, row00 + rstride); __builtin_amdgcn_sched_barrier(0); }
+  if constexpr (NS > 2) { LN_BWD_REQUEST(2, row00 + 2 * rstride); __builtin_amdgcn_sched_barrier(0); }
+  const int full = M / (rstride * NS);
+  int r0 = row00;
+  if (full > 0) {
+    LN_BWD_TRIP(r0)
+    r0 += NS * rstride;
+    for (int t = 1; t < full; ++t, r0 += NS * rstride) { LN_BWD_TRIP(r0) }
+  }
+  if (r0 < M) LN_BWD_SLOT(0, r0, false)
+  if constexpr (NS > 1) { if (r0 + rstride < M) LN_BWD_SLOT(1, r0 + rstride, false) }
+  if constexpr (NS > 2) { if (r0 + 2 * rstride < M) LN_BWD_SLOT(2, r0 + 2 * rstride, false) }
+#undef LN_BWD_TRIP
+#undef LN_BWD_SLOT
+#undef LN_BWD_REQUEST
   // block reduction over the 4 waves, then one partial row per block
 #pragma unroll
   for (int which = 0; which < 3; ++which) {
@@ -617,9 +674,15 @@ int ln_fwd_dispatch(int nch, dim3 grid, hipStream_t st, const void* x, int64_t l
 template <typename InT>
 int ln_bwd_dispatch(int nch, dim3 grid, hipStream_t st, const bf16_t* dy, int64_t ldd, const void* x, int64_t ldx, const float* mean, const float* rstd,
                     const float* gamma, int M, int D, bf16_t* dx, bf16_t* dxd, int64_t ldo, unsigned thr16, float inv_keep, uint64_t seed, uint64_t offset, float* ws) {
-#define LN_BWD_CASE(NC) case NC: ln_bwd_kernel<InT, NC><<<grid, dim3(256), 0, st>>>(dy, ldd, x, ldx, mean, rstd, gamma, M, D, dx, dxd, ldo, thr16, inv_keep, \
-      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), sam_get_rng_state(), ws); break;
+#define LN_BWD_LAUNCH(NC, FULL_, MODE_) ln_bwd_kernel<InT, NC, FULL_, MODE_><<<grid, dim3(256), 0, st>>>(dy, ldd, x, ldx, mean, rstd, gamma, M, D, dx, dxd, ldo, thr16, inv_keep, \
+      (unsigned)seed, (unsigned)(seed >> 32), (unsigned)offset, (unsigned)(offset >> 32), sam_get_rng_state(), ws)
+#define LN_BWD_CASE(NC) case NC: \
+    if (D == 256 * NC) { if (mode == 2) LN_BWD_LAUNCH(NC, true, 2); else if (mode == 1) LN_BWD_LAUNCH(NC, true, 1); else LN_BWD_LAUNCH(NC, true, 0); } \
+    else { if (mode == 2) LN_BWD_LAUNCH(NC, false, 2); else if (mode == 1) LN_BWD_LAUNCH(NC, false, 1); else LN_BWD_LAUNCH(NC, false, 0); } \
+    break;
+  const int mode = dxd ? (thr16 ? 2 : 1) : 0;
   switch (nch) { LN_BWD_CASE(1) LN_BWD_CASE(2) LN_BWD_CASE(3) LN_BWD_CASE(4) LN_BWD_CASE(5) LN_BWD_CASE(6) LN_BWD_CASE(7) LN_BWD_CASE(8) default: return SAM_ERR_UNSUPPORTED; }
+#undef LN_BWD_LAUNCH
 #undef LN_BWD_CASE
   return SAM_OK;
 }

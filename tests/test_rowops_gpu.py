@@ -46,7 +46,8 @@ def test_layernorm_golden_primitives():
 
 
 @pytest.mark.parametrize("M,D,in_dtype", [(1000, 768, torch.bfloat16), (37, 768, torch.float32), (5, 3072, torch.bfloat16), (130, 256, torch.bfloat16),
-                                         (1, 8, torch.bfloat16), (3, 2048, torch.bfloat16), (2049, 768, torch.bfloat16)])      # one row, the widest row, one row past 512 x 4
+                                         (1, 8, torch.bfloat16), (3, 2048, torch.bfloat16), (2049, 768, torch.bfloat16),      # one row, the widest row, one row past 512 x 4
+                                         (13001, 768, torch.bfloat16), (9000, 1024, torch.bfloat16)])     # two full trips of the backward's 3-slot (2-slot) row ring + a ragged rest
 @pytest.mark.parametrize("p_drop", [0.0, 0.1])
 def test_layernorm_fwd_bwd(M, D, in_dtype, p_drop):
     ops, capi = _mods()
@@ -84,6 +85,25 @@ def test_layernorm_fwd_bwd(M, D, in_dtype, p_drop):
     dg2 = dg.clone()
     ops.layernorm_bwd(dy.cuda(), x.cuda(), mean, rstd, w.cuda(), dg2, db.clone())
     assert torch.allclose(dg2, 2 * dg, rtol=1e-5, atol=1e-5)
+
+
+def test_wave_sum_is_the_xor_butterfly_bit_for_bit():
+    """wave_sum (common.h) runs the xor-butterfly 32, 16, 8, 4, 2, 1 through v_permlane swaps and DPP instead of ds_bpermute: the LayerNorm forward's row mean,
+    which is wave_sum(lane partials) / D, must equal an fp32 emulation of exactly that addition order (lane l owns the 4-element chunks l, l + 64, l + 128)"""
+    ops, _ = _mods()
+    M, D = 64, 768
+    x = rnd((M, D), 21, 3.0, torch.float32)
+    _, mean, _ = ops.layernorm_fwd(x.cuda(), torch.ones(D).cuda(), torch.zeros(D).cuda(), 1e-12)
+    v = x.numpy().reshape(M, 3, 64, 4)                       # [row, j, lane, e]
+    s = np.zeros((M, 64), np.float32)
+    for j in range(3):
+        s = s + ((v[:, j, :, 0] + v[:, j, :, 1]) + (v[:, j, :, 2] + v[:, j, :, 3]))
+    lanes = np.arange(64)
+    for o in (32, 16, 8, 4, 2, 1):
+        s = s + s[:, lanes ^ o]
+    assert (s == s[:, :1]).all()                             # every lane ends with the same bits
+    want = s[:, 0] / np.float32(D)
+    assert np.array_equal(mean.cpu().numpy().view(np.uint32), want.view(np.uint32))
 
 
 def test_colsum():
