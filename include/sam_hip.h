@@ -159,7 +159,9 @@ typedef struct sam_gemm_desc {
   sam_ln_fuse* ln;       /* optional (NULL = none): see sam_ln_fuse */
 } sam_gemm_desc;
 int sam_gemm_bf16(const sam_gemm_desc* d, void* stream);
-/* up to 12 independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C, SAM_EPI_NONE, no split) in ONE grid: the four
+/* up to 12 (20 when the 8-wave kernel takes the set: see the workspace note below) independent wgrad-layout problems (a_kcontig = b_kcontig = 0, fp32 C,
+ * SAM_EPI_NONE, no split) in ONE grid -- problems of different depth K may be mixed: the tiles of the deepest ones are dispatched first, one per CU, the
+ * shallow ones fill the CUs that round leaves idle (an MMT layer pair, 216 tiles x 182 k-tiles, together with TextBert's 324 tiles x 20).  E.g. the four
  * weight gradients of an encoder layer (dWqkv, dWo, dW1, dW2: 432 tiles of 128x128) fill the 512 resident block slots in a single
  * round, which makes split-K and its reduction pass unnecessary.  bias_grad is honoured per problem. */
 int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);

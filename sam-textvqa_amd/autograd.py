@@ -458,6 +458,8 @@ class DeferredWgrads:
     Their data-parallel regions are reported done after that launch, in backward order."""
     jobs, layers, acc = [], [], None
     late_stream, late = None, []
+    side_stream = None
+    held = []                   # [(jobs, layers, acc, event)]: the MMT's last group, waiting for TextBert's problems (flush)
     late_armed = False          # set by whoever will call join() before it reads the gradients (Trainer._eager_step); plain autograd use never leaves the issuing stream
 
     @classmethod
@@ -476,11 +478,39 @@ class DeferredWgrads:
 
     @classmethod
     def flush(cls, late=False):
-        if not cls.jobs:
+        if not cls.jobs and not cls.held:
             return
         jobs, layers, acc = cls.jobs, cls.layers, cls.acc
         cls.jobs, cls.layers, cls.acc = [], [], None
-        if late and cls.late_armed and jobs[0][0].is_cuda and wgrad_late_enabled():
+        armed = late and cls.late_armed and jobs and jobs[0][0].is_cuda and wgrad_late_enabled()
+        if armed and wgrad_merge_enabled() and not cls.held:
+            # the group that closes the MMT's backward is HELD: TextBert's three 1280-row layers (12 shallow problems: 324 tiles of 20 k-tiles, a 90 us launch
+            # that fills the chip 1.3 times) join it in ONE launch of 20 problems -- the pair's 216 deep tiles take 216 CUs for ~300 us, TextBert's tiles
+            # run on the 40 CUs that round leaves idle (csrc/gemm8w.hip, n_long).  The launch goes out where TextBert's flush happens (its embedding
+            # block's backward, on the side stream), after an event recorded here; Trainer joins that stream before it reads a gradient.
+            if parallel.active_reducer is not None and ops.LnFinalizeQueue.defer:     # (the layers' LayerNorm partial sums: finalized where they were written)
+                ops.LnFinalizeQueue.flush()
+                if torchops.enabled():
+                    torchops.ns().ln_finalize_flush()
+            ev = torch.cuda.Event()
+            ev.record()
+            cls.held = [(jobs, layers, acc, ev)]
+            return
+        if cls.held:
+            hjobs, hlayers, hacc, ev = cls.held[0]
+            cls.held = []
+            torch.cuda.current_stream().wait_event(ev)
+            if jobs and hacc == acc and len(hjobs) + len(jobs) <= 20:
+                jobs, layers = hjobs + jobs, hlayers + layers
+            else:                                   # (nothing to merge with, or not mergeable: the held group goes out by itself)
+                ops.wgrad_grouped(hjobs, accumulate=hacc)
+                for layer in hlayers:
+                    region_done(getattr(layer, "_sam_region_id", None))
+            cls.late.append(hjobs)                  # operands of the held group were allocated on another stream: alive until join()
+            cls.late_stream = torch.cuda.current_stream()
+            if not jobs:
+                return
+        elif armed:
             # the group that closes the MMT's backward (its first layers): nothing on the rest of the backward path reads these weight gradients, and what
             # follows on the issuing stream is the tail's chain of small kernels (embedding blocks, object / OCR encoders, TextBert's 1280-row layers).
             # The ~0.3 ms launch runs on a stream of its own next to that chain instead of in front of it; Trainer joins it before the gradient norm.
@@ -489,8 +519,9 @@ class DeferredWgrads:
                 if torchops.enabled():
                     torchops.ns().ln_finalize_flush()
             cur = torch.cuda.current_stream()
-            if cls.late_stream is None:
-                cls.late_stream = torch.cuda.Stream()
+            if cls.side_stream is None:
+                cls.side_stream = torch.cuda.Stream()
+            cls.late_stream = cls.side_stream
             cls.late_stream.wait_stream(cur)
             with torch.cuda.stream(cls.late_stream):
                 ops.wgrad_grouped(jobs, accumulate=acc)
@@ -512,6 +543,7 @@ class DeferredWgrads:
     @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
+        cls.held = []
         if cls.late:                 # a launch may still be reading its operands on the late stream: the issuing stream waits before they are dropped
             try:
                 torch.cuda.current_stream().wait_stream(cls.late_stream)
@@ -522,6 +554,10 @@ class DeferredWgrads:
 
 def wgrad_late_enabled():
     return os.environ.get("SAM_WGRAD_LATE", "1") != "0"
+
+
+def wgrad_merge_enabled():
+    return os.environ.get("SAM_WGRAD_MERGE_TB", "1") != "0"
 
 
 def defer_wgrad_enabled():

@@ -160,9 +160,9 @@ __device__ __forceinline__ unsigned hidden_dropout_row_key(unsigned row, unsigne
   return dropout_row_key(row, off_lo, off_hi, seed_lo ^ 0x5bd1e995u, seed_hi ^ 0x1b873593u);
 }
 // (the ds_bpermute butterfly: what every row kernel outside the LayerNorm pair still uses.  wave_sum_v is bit-identical to it -- tests/test_rowops_gpu.py
-// and tools/debug/l2norm_bits.py emulate the addition order in fp32 and compare bits -- but moving embed.hip's l2norm kernels onto it changed
-// test_incremental_beam_steps_decode_like_the_full_recompute deterministically, also under AMD_SERIALIZE_KERNEL=3 and with an s_nop 4 in front of the
-// first swap; not understood, so those callers stay here)
+// and tools/debug/l2norm_bits.py emulate the addition order in fp32 and compare bits, tools/debug/l2norm_unaligned.py checks the scalar kernel on the OCR
+// slices -- but with embed.hip's l2norm kernels on it test_incremental_beam_steps_decode_like_the_full_recompute fails deterministically (incremental and
+// full beam steps then disagree), also under AMD_SERIALIZE_KERNEL=3 and with an s_nop 4 in front of the first swap; not understood, so those callers stay here)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -491,8 +491,8 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
 }  // namespace
 
 extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream) {
-  SAM_REQUIRE(descs && count >= 1 && count <= SAM_MAX_GROUP, "sam_gemm_bf16_grouped: 1..%d problems", SAM_MAX_GROUP);
-  GroupArgs g = {};
+  SAM_REQUIRE(descs && count >= 1 && count <= SAM_MAX_GROUP8, "sam_gemm_bf16_grouped: 1..%d problems", SAM_MAX_GROUP8);
+  GroupArgs g = {};             // (the 4-wave kernel's arguments: up to SAM_MAX_GROUP problems; larger sets exist for the 8-wave kernel only)
   g.count = count;
   int total = 0;
   static int bm_env = -1;
@@ -505,6 +505,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     SAM_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0 && d->A && d->B && d->C, "sam_gemm_bf16_grouped: problem %d is empty", q);
     SAM_REQUIRE(d->M % 8 == 0 && d->N % 8 == 0 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->ldc % 4 == 0, "sam_gemm_bf16_grouped: problem %d: M, N, lda, ldb must be multiples of 8", q);
     SAM_REQUIRE(((uintptr_t)d->A % 16 == 0) && ((uintptr_t)d->B % 16 == 0) && ((uintptr_t)d->C % 16 == 0), "sam_gemm_bf16_grouped: problem %d: operands must be 16-byte aligned", q);
+    if (q >= SAM_MAX_GROUP) continue;
     GemmArgs& a = g.a[q];
     a.M = d->M; a.N = d->N; a.K = d->K;
     a.A = (const bf16_t*)d->A; a.lda = d->lda; a.B = (const bf16_t*)d->B; a.ldb = d->ldb; a.C = d->C; a.ldc = d->ldc;
@@ -522,7 +523,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
     g.start[q] = total;
     total += (a.tiles_m * a.tiles_n + 7) / 8 * 8;     // keep every problem's first block on XCD 0
   }
-  g.start[count] = total;
+  if (count <= SAM_MAX_GROUP) g.start[count] = total;
   // first choice: the 8-wave kernel with in-launch pair exchange (gemm8w.hip); it declines (K % 64, no workspace, tile counts it is not built for)
   // without touching the error string.  descs[0].force_tile: 128 = this file's 4-wave kernel, 1256 = the 8-wave kernel or an error.
   {
@@ -536,6 +537,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
       SAM_REQUIRE(rc == SAM_ERR_UNSUPPORTED && ft != 1256, "sam_gemm_bf16_grouped: the 8-wave grouped kernel cannot run this problem set (K %% 64, workspace, tile count)");
     }
   }
+  SAM_REQUIRE(count <= SAM_MAX_GROUP, "sam_gemm_bf16_grouped: more than %d problems need the 8-wave kernel, which declined this set", SAM_MAX_GROUP);
   static bool once = false;
   if (!once) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2);
@@ -551,7 +553,7 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
 }
 
 extern "C" int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count) {
-  if (!descs || count < 1 || count > SAM_MAX_GROUP) return 0;
+  if (!descs || count < 1 || count > SAM_MAX_GROUP8) return 0;
   int tiles = 0;
   for (int q = 0; q < count; ++q) tiles += ((descs[q].M + 255) / 256) * ((descs[q].N + 255) / 256);
   return gemm8w_ws_bytes(tiles);
@@ -668,7 +670,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1192, 1256, 1448 or 3192");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192 || ft == 1128, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1128, 1192, 1256, 1448 or 3192");
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T

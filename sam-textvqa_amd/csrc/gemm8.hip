@@ -37,7 +37,7 @@ __device__ __forceinline__ void tile_origin(const GemmArgs& p, int id, int& m0, 
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT>
-__global__ __launch_bounds__(512, 2) void gemm8_kernel(GemmArgs p) {
+__global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_kernel(GemmArgs p) {
   constexpr int TM = BM / 32, TN = BN / 64, SA = BM / 64, SB = BN / 64, RB = TM / 2;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(BM % 64 == 0 && BN % 64 == 0 && SB <= 4, "tile shape");
@@ -488,7 +488,8 @@ int launch8(GemmArgs a, int n_cu, hipStream_t st) {
   }
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int tiles = a.tiles_m * a.tiles_n;
-  gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDS, st>>>(a);
+  const int slots = BM * BN <= 128 * 128 ? 2 * n_cu : n_cu;      // the 128 x 128 configuration (64 KB of stages, <= 128 VGPRs) runs two blocks per CU
+  gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT><<<dim3(tiles < slots ? tiles : slots), dim3(512), LDS, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -503,15 +504,16 @@ int launch8(GemmArgs a, int n_cu, hipStream_t st) {
 // (732 tiles = 2.86 rounds of 0.75-size tiles instead of 2.16 -> 3 rounds of full-size ones; 64 output columns per wave = whole 128-byte lines:
 // tk 1.27, es 4.9 / 5.9; FFN1 forward 113 -> 88 -> 81 us), 192^2 for N = 768 (138 tiles of 256^2 would leave half the chip idle).
 struct TileCfg { int bm, bn; float tk, es, es2; };
-constexpr TileCfg kCfg[3] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.7f, 7.2f}, {192, 256, 1.27f, 4.9f, 5.9f}};
+constexpr TileCfg kCfg[4] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.7f, 7.2f}, {192, 256, 1.27f, 4.9f, 5.9f}, {128, 128, 0.f, 0.f, 0.f}};
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int pick8(const GemmArgs& a, int tile, hipStream_t st) {
   const int n_cu = device_cu_count();
   int best = -1; float best_score = 0.f;
-  for (int c = 0; c < 3; ++c) {
-    // 1192 / 1256 / 1448: force 192x192 / 256x256 / 192x256; 3192: 192x192 with the deferred epilogue (measured slower)
+  for (int c = 0; c < 4; ++c) {
+    // 1192 / 1256 / 1448 / 1128: force 192x192 / 256x256 / 192x256 / 128x128; 3192: 192x192 with the deferred epilogue (measured slower)
     if (tile != 0 && (tile == 1448 ? c != 2 : (c == 2 || tile % 1000 != kCfg[c].bm))) continue;
+    if (c == 3 && tile == 0) continue;          // 128x128: forced only (see pick_small below)
     const int tiles = ((a.M + kCfg[c].bm - 1) / kCfg[c].bm) * ((a.N + kCfg[c].bn - 1) / kCfg[c].bn);
     const int rounds = (tiles + n_cu - 1) / n_cu;
     const bool two_out = EPI == SAM_EPI_BIAS_GELU_GRAD || EPI == SAM_EPI_BIAS_GELU;
@@ -520,6 +522,7 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     const float score = 1.0f / t;
     if (best < 0 || score > best_score) { best = c; best_score = score; }
   }
+  if (best == 3) return launch8<128, 128, AKC, BKC, EPI, OutT>(a, n_cu, st);
   if (best == 0) return launch8<256, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);
   if (best == 2) return launch8<192, 256, AKC, BKC, EPI, OutT>(a, n_cu, st);
   if (best == 1) {
@@ -543,7 +546,14 @@ int samgemm::gemm8_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, in
   if (a.K % BK != 0 || a.split_k > 1 || a.bias_grad != nullptr || c_is_f32) return SAM_ERR_UNSUPPORTED;
   const int64_t a_rows = (lay & 2) ? a.M : a.K, b_rows = (lay & 1) ? a.N : a.K;
   if (a_rows * a.lda * 2 >= (int64_t)0x7fffffff || b_rows * a.ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;
-  if (tile == 0 && ((int64_t)((a.M + 191) / 192) * ((a.N + 191) / 192) < 160 || a.K < 256)) return SAM_ERR_UNSUPPORTED;   // small grids: the 4-wave kernels (2-4 blocks per CU)
+  if (tile == 0 && ((int64_t)((a.M + 191) / 192) * ((a.N + 191) / 192) < 160 || a.K < 256)) {
+    // small grids: the 4-wave kernels (2-4 blocks per CU) -- except a short-K problem whose 128 x 128 tiles fill the chip once (TextBert's FFN1 forward and
+    // FFN2 dgrad, 1280 x 3072 x 768: 240 tiles, two blocks per CU; cold operands 15.4 / 14.1 us against 18.2 / 17.6 for the 64 x 64 four-wave tiles.  At MMT
+    // size the configuration loses to the larger tiles on every shape -- 56 / 91 / 91 us for QKV / FFN1 / FFN2 against 49 / 82 / 69: twice the LDS traffic per flop)
+    const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.K >= 256 && a.K <= 1024 && t128 >= 200 && t128 <= 2 * device_cu_count()) tile = 1128;
+    else return SAM_ERR_UNSUPPORTED;
+  }
   if (lay == 3) {
     if (e == SAM_EPI_NONE) return pick8<true, true, SAM_EPI_NONE, bf16_t>(a, tile, st);
     if (e == SAM_EPI_BIAS) return pick8<true, true, SAM_EPI_BIAS, bf16_t>(a, tile, st);

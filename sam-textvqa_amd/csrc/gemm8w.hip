@@ -30,9 +30,10 @@ struct WProb {
   int M, N, K, tiles_m, tiles_n, accumulate;
 };
 struct WArgs {
-  WProb p[samgemm::SAM_MAX_GROUP];
-  int tile_start[samgemm::SAM_MAX_GROUP + 1];
+  WProb p[samgemm::SAM_MAX_GROUP8];
+  int tile_start[samgemm::SAM_MAX_GROUP8 + 1];
   int count, split, dbg;
+  int n_long;          // > 0: the first n_long items (the tiles of the deepest problems, a multiple of 8) form a segment of their own (see below)
   float* ws;           // [tiles][2] slots of SLOT_FLOATS
   unsigned* flags;     // [tiles][2], zero between launches
 };
@@ -78,16 +79,25 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, g = lane >> 4;
   const int wr = wave >> 2, wc = wave & 3;
   // ---- block -> (problem, tile, k half)
+  // Mixed depths (an MMT pair, 216 tiles of 182 k-tiles, with TextBert's 324 tiles of 20): workgroups are dispatched in id order, so the first n_long
+  // ids take the deep tiles -- one per CU, all starting together, the lock-step panel sharing inside an XCD as before -- and the ids behind them
+  // the shallow ones: 40 go to the CUs the deep round leaves idle, the rest follow as those finish (7 rounds of ~35 us inside the deep round's 300).
+  // Each segment deals its items to the XCDs in contiguous runs (n_long is a multiple of 8: id % 8 is the XCD in both).
   const int nitem = w.tile_start[w.count] * w.split;
   int item;
   {
-    const int bid = blockIdx.x, q = nitem / 8, r = nitem % 8, xcd = bid % 8, loc = bid / 8;
-    item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    int bid = blockIdx.x, seg0 = 0, seglen = nitem;
+    if (w.n_long > 0) {
+      if (bid < w.n_long) seglen = w.n_long;
+      else { seg0 = w.n_long; seglen = nitem - w.n_long; bid -= w.n_long; }
+    }
+    const int q = seglen / 8, r = seglen % 8, xcd = bid % 8, loc = bid / 8;
+    item = seg0 + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
   }
   const int gtile = item / w.split, half = item - gtile * w.split;
   int pi = 0;
 #pragma unroll
-  for (int q = 1; q < samgemm::SAM_MAX_GROUP; ++q)
+  for (int q = 1; q < samgemm::SAM_MAX_GROUP8; ++q)
     if (q < w.count && gtile >= w.tile_start[q]) pi = q;
   const WProb& P = w.p[pi];
   const int tile = gtile - w.tile_start[pi];
@@ -276,9 +286,15 @@ int64_t gemm8w_ws_bytes(int tiles) { return (int64_t)tiles * 2 * SLOT_FLOATS * 4
 int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   WArgs w = {};
   w.count = count;
-  int tiles = 0, min_kt = 1 << 30;
+  int tiles = 0, min_kt = 1 << 30, max_k = 0;
+  // deepest problems first (stable): their tiles become the launch's first segment
+  int order[SAM_MAX_GROUP8];
+  for (int q = 0; q < count; ++q) { order[q] = q; max_k = descs[q].K > max_k ? descs[q].K : max_k; }
+  for (int a = 1; a < count; ++a)
+    for (int b = a; b > 0 && descs[order[b]].K > descs[order[b - 1]].K; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
+  int n_long = 0;
   for (int q = 0; q < count; ++q) {
-    const sam_gemm_desc* d = descs + q;
+    const sam_gemm_desc* d = descs + order[q];
     if (d->K % BK != 0 || d->M % 8 != 0 || d->N % 8 != 0 ) return SAM_ERR_UNSUPPORTED;
     if ((int64_t)d->K * d->lda * 2 >= (int64_t)0x7fffffff || (int64_t)d->K * d->ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;
     WProb& p = w.p[q];
@@ -287,6 +303,7 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
     p.tiles_m = (d->M + BM - 1) / BM; p.tiles_n = (d->N + BN - 1) / BN;
     w.tile_start[q] = tiles;
     tiles += p.tiles_m * p.tiles_n;
+    if (d->K == max_k) n_long = tiles;
     min_kt = d->K / BK < min_kt ? d->K / BK : min_kt;
   }
   w.tile_start[count] = tiles;
@@ -296,6 +313,7 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   // the resident set is still a prefix of the ids, every pair inside it completes and frees its CUs -- the wait cannot deadlock.
   w.split = (tiles * 2 <= n_cu && min_kt >= 8) ? 2 : 1;
   if (w.split == 1 && (tiles < n_cu / 2 || tiles > 4 * n_cu)) return SAM_ERR_UNSUPPORTED;      // too few tiles to fill the chip unsplit / a many-round grid: the 4-wave kernel
+  w.n_long = (w.split == 1 && n_long < tiles && n_long <= n_cu && n_long % 8 == 0 && max_k >= 4 * min_kt * BK) ? n_long : 0;
   if (w.split == 2) {
     const sam_gemm_desc* d0 = descs;
     if (!d0->ws || d0->ws_bytes < gemm8w_ws_bytes(tiles) || ((uintptr_t)d0->ws % 16) != 0) return SAM_ERR_UNSUPPORTED;

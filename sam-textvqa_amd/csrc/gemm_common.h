@@ -291,7 +291,8 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&
   else gemm_epilogue8_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
 }
 
-constexpr int SAM_MAX_GROUP = 12;        // problems per grouped weight-gradient launch (an encoder layer has 4; TextBert's three layers go out together)
+constexpr int SAM_MAX_GROUP = 12;        // problems per grouped weight-gradient launch of the 4-wave kernel (an encoder layer has 4; TextBert's three layers go out together)
+constexpr int SAM_MAX_GROUP8 = 20;       // ... of the 8-wave kernel (gemm8w.hip): an MMT pair (8) + TextBert's three layers (12) in one launch
 
 // CU count of the CURRENT device (cached per device ordinal: a process that drives several GPUs must not size grids from the first one it queried)
 inline int device_cu_count() {

@@ -104,8 +104,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> gemm_ln(const Tensor& a, const Tensor
 // dW += dy^T x (and db += colsum(dy)) for up to 8 jobs in one launch
 struct WgradJob { const Tensor* dy; const Tensor* x; const Tensor* dw; const Tensor* db; };
 void wgrad_grouped(const std::vector<WgradJob>& jobs, bool accumulate = true) {
-  sam_gemm_desc d[12] = {};
-  TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 12, "wgrad_grouped: 1..12 jobs");
+  sam_gemm_desc d[20] = {};
+  TORCH_CHECK(jobs.size() >= 1 && jobs.size() <= 20, "wgrad_grouped: 1..20 jobs");
   for (size_t q = 0; q < jobs.size(); ++q) {
     const WgradJob& j = jobs[q];
     d[q].M = (int32_t)j.dy->size(1); d[q].N = (int32_t)j.x->size(1); d[q].K = (int32_t)j.dy->size(0);
@@ -486,7 +486,7 @@ std::vector<Tensor> encoder_layer_bwd_nowgrad(const Tensor& dy_in, at::TensorLis
                                               int64_t heads, double scale, double p_attn, double p_hid, at::IntArrayRef seeds, bool need_dx, bool accumulate) {
   return encoder_layer_bwd_impl(dy_in, saved, allow, params, grads, batch, heads, scale, p_attn, p_hid, seeds, need_dx, accumulate, true);
 }
-// dW_q (+)= dy_q^T x_q (and db_q (+)= column sums of dy_q) for up to 12 problems in one launch
+// dW_q (+)= dy_q^T x_q (and db_q (+)= column sums of dy_q) for up to 20 problems in one launch
 void wgrad_grouped_op(at::TensorList dys, at::TensorList xs, at::TensorList dws, at::TensorList dbs, bool accumulate) {
   TORCH_CHECK(dys.size() == xs.size() && dys.size() == dws.size() && dys.size() == dbs.size(), "wgrad_grouped: list sizes differ");
   std::vector<WgradJob> jobs;

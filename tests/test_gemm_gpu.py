@@ -192,7 +192,7 @@ def test_both_tile_configs_all_layouts(tile):
     assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
 
 
-@pytest.mark.parametrize("tile", [1192, 3192, 1256, 1448])      # 3192: 192x192 with the deferred (sliced, LDS-staged) epilogue (opt-in: measured slower); 1448: 192x256
+@pytest.mark.parametrize("tile", [1192, 3192, 1256, 1448, 1128])      # 3192: 192x192 with the deferred (sliced, LDS-staged) epilogue (opt-in: measured slower); 1448: 192x256
 @pytest.mark.parametrize("M,N,K", [(3500, 3080, 128), (600, 520, 64), (4000, 2304, 192), (256, 256, 704), (11648, 768, 768)])
 def test_eight_wave_persistent_kernels(tile, M, N, K):
     """gemm8.hip (256x256 / 192x192 tiles, one block per CU walking several tiles): ragged M and N, one to eleven k-tiles per tile, more tiles
@@ -267,7 +267,7 @@ def test_grouped_wgrad_matches_individual():
         if db is not None:
             assert_close_bf16(db, dy.float().sum(0), ulps=0, name="12-problem grouped bias grad %d" % k)
     with pytest.raises(capi.SamHipError):
-        ops.wgrad_grouped(jobs * 4)         # more than 12 problems
+        ops.wgrad_grouped(jobs * 6)         # more than 20 problems
 
 
 def _wgrad_jobs(R, shapes, seed0=0, bias=(1, 3)):
@@ -325,6 +325,34 @@ def test_grouped_wgrad_overwrite_equals_accumulate_into_zero(R, force):
     for a, b in zip(zero, junk):
         assert torch.equal(a[2], b[2])
         assert a[3] is None or torch.equal(a[3], b[3])
+
+
+def test_grouped_wgrad_mixed_depths_in_one_launch():
+    """an MMT layer pair (8 problems, 216 tiles, deep K) and TextBert's three layers (12 problems, 324 tiles, shallow K) as ONE launch of 20 problems: the deep
+    tiles are dispatched first, one per CU, the shallow ones fill the idle CUs and follow as they finish (gemm8w.hip, n_long).  Against fp32, with fused bias
+    gradients, overwrite mode, and bit-identical to the two separate launches (every tile sums its own K range whole, in the same order)."""
+    ops, capi = _mods()
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    deep, deep_ref = _wgrad_jobs(2048, shapes * 2, seed0=100, bias=(0, 3, 5))
+    shal, shal_ref = _wgrad_jobs(320, shapes * 3, seed0=200, bias=(1, 2, 7, 11))
+    mixed = shal[:5] + deep + shal[5:]                    # any order: the launch sorts by depth
+    ops.wgrad_grouped(mixed, force_tile=1256)
+    for (dy, x, dw, db), (rw, rb) in zip(deep + shal, deep_ref + shal_ref):
+        assert_close_bf16(dw, rw, ulps=0, name="mixed-depth grouped wgrad")
+        if db is not None:
+            assert_close_bf16(db, rb, ulps=0, name="mixed-depth grouped bias grad")
+    d2, _ = _wgrad_jobs(2048, shapes * 2, seed0=100, bias=(0, 3, 5))
+    s2, _ = _wgrad_jobs(320, shapes * 3, seed0=200, bias=(1, 2, 7, 11))
+    ops.wgrad_grouped(d2, force_tile=1256)
+    ops.wgrad_grouped(s2, force_tile=1256)
+    for a, b in zip(deep + shal, d2 + s2):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
+    junk = [(dy, x, torch.full_like(dw, 3.5), None if db is None else torch.full_like(db, -1.0)) for dy, x, dw, db in mixed]
+    ops.wgrad_grouped(junk, force_tile=1256, accumulate=False)
+    zero = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in mixed]
+    ops.wgrad_grouped(zero, force_tile=1256)
+    for a, b in zip(zero, junk):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
 
 
 def test_grouped_wgrad_eight_wave_ragged_and_unsplit():

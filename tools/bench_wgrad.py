@@ -37,5 +37,37 @@ def main():
             print(name, "failed:", e, flush=True)
 
 
+def mixed():
+    """an MMT layer pair (R rows) and TextBert's three layers (1280 rows): two launches against one launch of 20 problems"""
+    R = 64 * 182
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    g = torch.Generator(device="cuda").manual_seed(0)
+    def mk(rows, n):
+        out = []
+        for _ in range(n):
+            for m, k in shapes:
+                dy = (torch.randn(rows, m, device="cuda", generator=g) * 0.5).bfloat16()
+                x = (torch.randn(rows, k, device="cuda", generator=g) * 0.5).bfloat16()
+                out.append((dy, x, torch.zeros(m, k, device="cuda"), torch.zeros(m, device="cuda")))
+        return out
+    pair, tb = mk(R, 2), mk(1280, 3)
+    fl = sum(2.0 * j[0].shape[0] * j[0].shape[1] * j[1].shape[1] for j in pair + tb)
+    def t(fn, n=30):
+        for _ in range(3): fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n): fn()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n
+    a = t(lambda: ops.wgrad_grouped(pair, accumulate=False))
+    b = t(lambda: ops.wgrad_grouped(tb, accumulate=False))
+    c = t(lambda: ops.wgrad_grouped(pair + tb, accumulate=False))
+    print("pair alone %.1f us, TextBert alone %.1f us (sum %.1f us, %.1f TFLOP/s); one launch of 20 problems %.1f us (%.1f TFLOP/s)" % (a, b, a + b, fl / (a + b) * 1e-6, c, fl / c * 1e-6))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "mixed":
+        mixed()
+        sys.exit(0)
     main()
