@@ -220,15 +220,29 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_group_kernel(GroupArgs g
   gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT>(g.a[prob], local);
 }
 
+// a (+)= ws[s][i] for s = 1 .. S-1 in that order, the loads of four partials requested together (the plain loop leaves ONE load in flight per thread and
+// waits for it before the next: S - 1 memory round trips in a row in kernels that are nothing but that); the additions keep the order of the plain loop
+__device__ __forceinline__ void splitk_sum(float4& a, const float* ws, int S, int64_t MN, int64_t i4) {
+  int s = 1;
+  for (; s + 4 <= S; s += 4) {
+    float4 b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) b[u] = reinterpret_cast<const float4*>(ws + (int64_t)(s + u) * MN)[i4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a.x += b[u].x; a.y += b[u].y; a.z += b[u].z; a.w += b[u].w; }
+  }
+  for (; s < S; ++s) {
+    const float4 b = reinterpret_cast<const float4*>(ws + (int64_t)s * MN)[i4];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  }
+}
+
 // C[m,n] += sum_s ws[s][m,n]; bias_grad[m] += sum_s wsb[s][m]   (fixed summation order: reproducible)
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int S, int M, int N, float* C, int64_t ldc, float* bias_grad) {
   const int64_t mn4 = (int64_t)M * N / 4;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (int64_t)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4*>(ws)[i];
-    for (int s = 1; s < S; ++s) {
-      const float4 b = reinterpret_cast<const float4*>(ws + (int64_t)s * M * N)[i];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
+    splitk_sum(a, ws, S, (int64_t)M * N, i);
     const int64_t e = i * 4, m = e / N, n = e - m * N;
     float4* dst = reinterpret_cast<float4*>(C + m * ldc + n);
     const float4 c = *dst;
@@ -254,10 +268,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* ws, i
   if (EPI == SAM_EPI_BIAS_DROPOUT_RES) rng_resolve(p.rng_state, seed_lo, seed_hi, off_lo, off_hi);
   for (int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x; i4 < mn4; i4 += (int64_t)gridDim.x * 256) {
     float4 a = reinterpret_cast<const float4*>(ws)[i4];
-    for (int s = 1; s < S; ++s) {
-      const float4 b = reinterpret_cast<const float4*>(ws + (int64_t)s * MN)[i4];
-      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    }
+    splitk_sum(a, ws, S, MN, i4);
     const int64_t e = i4 * 4;
     const int m = (int)(e / p.N), n = (int)(e - (int64_t)m * p.N);
     float v[4] = {a.x, a.y, a.z, a.w};
