@@ -499,6 +499,21 @@ class DeferredWgrads:
         if cls.held:
             hjobs, hlayers, hacc, ev = cls.held[0]
             cls.held = []
+            if jobs and hacc == acc and len(hjobs) + len(jobs) <= 20 and os.environ.get("SAM_WGRAD_MERGE_STREAM", "1") != "0":
+                # the launch of 20 goes to a stream of its own: what follows on the issuing stream (TextBert's embedding block: five small kernels, 45 us)
+                # runs beside it instead of behind it; Trainer joins before the gradient norm
+                cur = torch.cuda.current_stream()
+                if cls.side_stream is None:
+                    cls.side_stream = torch.cuda.Stream()
+                cls.side_stream.wait_stream(cur)
+                cls.side_stream.wait_event(ev)
+                with torch.cuda.stream(cls.side_stream):
+                    ops.wgrad_grouped(hjobs + jobs, accumulate=acc)
+                    for layer in hlayers + layers:
+                        region_done(getattr(layer, "_sam_region_id", None))
+                cls.late.append(hjobs + jobs)
+                cls.late_stream = cls.side_stream
+                return
             torch.cuda.current_stream().wait_event(ev)
             if jobs and hacc == acc and len(hjobs) + len(jobs) <= 20:
                 jobs, layers = hjobs + jobs, hlayers + layers

@@ -341,10 +341,10 @@ class Trainer:
         if side is not None:
             torch.cuda.current_stream().wait_stream(side)      # TextBert / pointer-net backward ran there: join before the norm and the update
         DeferredWgrads.flush()                                  # (normally empty: TextBert's embedding block flushed it in its backward)
+        if defer_ln:
+            self._ln_flush()                                    # (before the join: the batched finalize runs beside the last weight-gradient launch, not behind it)
         DeferredWgrads.join()                                   # the MMT's last weight-gradient group ran on a stream of its own
         parallel.active_reducer = None
-        if defer_ln:
-            self._ln_flush()
         if self.reducer is not None:
             timing = self.measure_comm and not torch.cuda.is_current_stream_capturing()      # (timing events cannot be recorded into a capture)
             if timing:
