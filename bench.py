@@ -479,9 +479,12 @@ def main():
     gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
+    host_ms = []
     for j in range(args.steps):
+        h0 = time.perf_counter()
         loss = trainer.step(next_batch(args.warmup + j, batch))
         marks[j + 1].record()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     if parallel.dist.is_initialized():
         parallel.dist.barrier()
@@ -513,6 +516,9 @@ def main():
         "ms_per_step_median": round(statistics.median(step_ms), 3),           # GPU time between per-step events on the launch stream (the value above is the wall-clock mean)
         "ms_per_step_p10_p90_max": [round(sorted(step_ms)[len(step_ms) // 10], 3), round(sorted(step_ms)[(9 * len(step_ms)) // 10], 3), round(max(step_ms), 3)],
         "slow_steps": [[j, round(t, 2)] for j, t in enumerate(step_ms) if t > 1.15 * statistics.median(step_ms)][:12],
+        # host time of each step() call (enqueue only: nothing in it synchronises): a slow GPU-side step next to a slow host call a few steps earlier is a host
+        # pause the submission queue could not absorb; next to an ordinary host call it happened on the device side
+        "host_ms_per_call_median_max": [round(statistics.median(host_ms), 3), round(max(host_ms), 2), int(max(range(len(host_ms)), key=host_ms.__getitem__))],
         "batches_rotated": len(rot),
         "word_table_rows_touched": int(trainer.sparse[3].sum().item()) if getattr(trainer, "sparse", None) is not None else None,
         "train_gflop_per_sample": round(train_gflop(shape, len(layers), args.vocab), 2),
