@@ -518,6 +518,7 @@ def main():
         "slow_steps": [[j, round(t, 2)] for j, t in enumerate(step_ms) if t > 1.15 * statistics.median(step_ms)][:12],
         # host time of each step() call (enqueue only: nothing in it synchronises): a slow GPU-side step next to a slow host call a few steps earlier is a host
         # pause the submission queue could not absorb; next to an ordinary host call it happened on the device side
+        "first_steps_gpu_host_ms": [[round(step_ms[j], 2), round(host_ms[j], 2)] for j in range(min(4, len(step_ms)))],
         "host_ms_per_call_median_max": [round(statistics.median(host_ms), 3), round(max(host_ms), 2), int(max(range(len(host_ms)), key=host_ms.__getitem__))],
         "batches_rotated": len(rot),
         "word_table_rows_touched": int(trainer.sparse[3].sum().item()) if getattr(trainer, "sparse", None) is not None else None,
