@@ -483,15 +483,13 @@ class DeferredWgrads:
         jobs, layers, acc = cls.jobs, cls.layers, cls.acc
         cls.jobs, cls.layers, cls.acc = [], [], None
         armed = late and cls.late_armed and jobs and jobs[0][0].is_cuda and wgrad_late_enabled()
-        if armed and wgrad_merge_enabled() and not cls.held:
+        # (not under a gradient reducer: the held group's buckets would leave only after the launch of 20, at the very end of the backward, instead of
+        # underneath TextBert's chain -- ~60 MB more of exposed all-reduce per step for 0.02 ms of compute)
+        if armed and wgrad_merge_enabled() and not cls.held and parallel.active_reducer is None:
             # the group that closes the MMT's backward is HELD: TextBert's three 1280-row layers (12 shallow problems: 324 tiles of 20 k-tiles, a 90 us launch
             # that fills the chip 1.3 times) join it in ONE launch of 20 problems -- the pair's 216 deep tiles take 216 CUs for ~300 us, TextBert's tiles
             # run on the 40 CUs that round leaves idle (csrc/gemm8w.hip, n_long).  The launch goes out where TextBert's flush happens (its embedding
             # block's backward, on the side stream), after an event recorded here; Trainer joins that stream before it reads a gradient.
-            if parallel.active_reducer is not None and ops.LnFinalizeQueue.defer:     # (the layers' LayerNorm partial sums: finalized where they were written)
-                ops.LnFinalizeQueue.flush()
-                if torchops.enabled():
-                    torchops.ns().ln_finalize_flush()
             ev = torch.cuda.Event()
             ev.record()
             cls.held = [(jobs, layers, acc, ev)]
