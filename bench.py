@@ -468,8 +468,8 @@ def main():
         one = torch.ones(1, dtype=torch.float32, device=dev)
         parallel.dist.all_reduce(one, group=trainer.reducer.group if trainer.reducer is not None else None)
         ranks_seen = int(round(one.item()))
-        parallel.dist.barrier()
-    torch.cuda.synchronize()
+    # host-side preparation (events, a full collection) BEFORE the bracket, so that nothing sits between the synchronize and the first launch.  (The first timed
+    # step still reads ~7.0 ms against 6.1: its event bracket contains the ~1 ms the host needs to submit the first graph to an idle GPU; steps 1-3 read 6.4 / 6.25 / 6.2.)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     # the cyclic collector stays off inside the timed region (a generation-2 pass over the model's object graph is a 10-20 ms host pause, i.e. two or three
     # steps of an idle GPU once every few hundred steps: seen as single 20 ms steps in `slow_steps`); a training loop does the same with gc.freeze()
@@ -477,6 +477,9 @@ def main():
     gc.collect()
     gc_was_on = gc.isenabled()
     gc.disable()
+    if parallel.dist.is_initialized():
+        parallel.dist.barrier()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     marks[0].record()
     host_ms = []
