@@ -455,7 +455,8 @@ class DeferredWgrads:
     """weight gradients of layers marked `_sam_defer_wgrad` (TextBert's three 1280-row layers: a grouped launch of four 18-GFLOP problems fills 216 of
     512 block slots for 38 us, three times in a row on the tail's critical chain) are queued by EncoderLayerFn.backward and run as ONE grouped launch of up
     to 12 problems when the embedding block below them starts its backward (EmbedLayerNormFn) -- or, failing that, when the Trainer joins the backward.
-    Their data-parallel regions are reported done after that launch, in backward order."""
+    Their data-parallel regions are reported done after that launch, in backward order.  Without a gradient reducer the MMT's last layer group waits for them
+    (`held`) and the two go out as one launch of 20 problems of mixed depth (flush)."""
     jobs, layers, acc = [], [], None
     late_stream, late = None, []
     side_stream = None
