@@ -229,6 +229,30 @@ def test_eight_wave_persistent_kernels(tile, M, N, K):
     assert torch.equal(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile))
 
 
+def test_short_k_problem_that_fills_the_chip_once_takes_the_two_block_configuration():
+    """TextBert's FFN1 forward / FFN2 dgrad (1280 x 3072 x 768: 240 tiles of 128 x 128) are sent to the 8-wave kernel's 128 x 128 two-blocks-per-CU configuration by
+    the default picker (gemm8.hip): same results as the forced configuration bit for bit, and as the 4-wave 64 x 64 kernel up to the accumulation order"""
+    ops, capi = _mods()
+    M, N, K = 1280, 3072, 768
+    x, w = rnd((M, K), 71), rnd((N, K), 72, 0.05)
+    b = torch.randn(N, generator=torch.Generator().manual_seed(73)) * 0.1
+    xg, wg, bg = x.cuda(), w.cuda(), b.cuda()
+    outs = {}
+    for tile in (0, 1128, 64):
+        pre = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+        h = ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_GELU_GRAD, bias=bg, aux_out=pre, force_tile=tile)
+        outs[tile] = (h, pre)
+    assert torch.equal(outs[0][0], outs[1128][0]) and torch.equal(outs[0][1], outs[1128][1])
+    assert_close_bf16(outs[0][0], outs[64][0].float(), ulps=2, name="128x128 vs 64x64 gelu")
+    ref = x.float() @ w.float().t() + b
+    assert_close_bf16(outs[0][0], gelu(ref), name="fwd gelu"); assert_close_bf16(outs[0][1], dgelu(ref), name="fwd gelu'")
+    wT, aux = rnd((K, N), 74, 0.05), rnd((M, N), 75)
+    d0 = ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=aux.cuda())
+    d1 = ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=aux.cuda(), force_tile=1128)
+    assert torch.equal(d0, d1)
+    assert_close_bf16(d0, (x.float() @ wT.float()) * aux.float(), name="dgrad * aux")
+
+
 def test_eight_wave_kernels_decline_what_they_cannot_do():
     ops, capi = _mods()
     x, w = rnd((512, 72), 71).cuda(), rnd((512, 72), 72).cuda()
