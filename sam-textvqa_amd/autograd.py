@@ -113,7 +113,8 @@ class LinearFn(Function):
             dp = torch.zeros((dy2.shape[0], n_pad), dtype=BF16, device=dy.device)
             dp[:, :n] = dy2
             dy2 = dp
-        ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)   # dW += dy^T x ; db += colsum(dy)
+        if not DeferredWgrads.add_extra((dy2, x2, gv, dbv, True)):
+            ops.gemm(dy2, x2, a_kcontig=False, b_kcontig=False, out=gv, accumulate=True, split_k=-1, bias_grad=dbv)   # dW += dy^T x ; db += colsum(dy)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, wv, b_kcontig=False)[:, :ctx.in_shape[-1]]                    # dx = dy W
@@ -434,6 +435,7 @@ class GradBarrierFn(Function):
     def backward(ctx, g):
         red = parallel.active_reducer
         if red is not None:
+            DeferredWgrads.flush_extras()        # (the heads' weight gradients must be final before their regions close)
             red.barrier_hit(ctx.name)
         return g, None
 
@@ -461,6 +463,7 @@ class DeferredWgrads:
     late_stream, late = None, []
     side_stream = None
     held = []                   # [(jobs, layers, acc, event)]: the MMT's last group, waiting for TextBert's problems (flush)
+    extras = []                 # weight gradients of nn.Linear sites outside the encoder layers (classifier, pointer-net q / k), waiting for the next MMT group
     late_armed = False          # set by whoever will call join() before it reads the gradients (Trainer._eager_step); plain autograd use never leaves the issuing stream
 
     @classmethod
@@ -478,8 +481,24 @@ class DeferredWgrads:
             cls.flush(late=bool(getattr(layer, "_sam_wgrad_late", False)))
 
     @classmethod
+    def add_extra(cls, job):
+        """the classifier's and the pointer network's weight gradients (three GEMMs of 9-60 tiles x 12-50 k-tiles + their split-K reductions: ~60 us of launches at
+        the head of the backward's chain) ride on the 40 CUs the MMT's next layer-pair launch leaves idle (gemm8w.hip: shallow problems behind the deep ones).
+        Only inside Trainer._eager_step (which flushes whatever is left), on the device, for shapes the grouped kernels take; False = the caller launches it itself.
+        Their data-parallel regions are closed by the encoder-output barriers, i.e. after the MMT's whole backward: the launch they join is long done by then."""
+        dy, x, dw, db, _ = job
+        if not (cls.late_armed and dy.is_cuda and os.environ.get("SAM_DEFER_HEAD_WGRAD", "1") != "0" and defer_mmt_pairs_active()):
+            return False
+        if dy.shape[0] % 64 or dy.shape[1] % 8 or x.shape[1] % 8 or dy.stride(0) % 8 or x.stride(0) % 8 or dw.stride(0) % 4 or len(cls.extras) >= 6:
+            return False
+        if dy.data_ptr() % 16 or x.data_ptr() % 16 or dw.data_ptr() % 16:
+            return False
+        cls.extras.append(job)
+        return True
+
+    @classmethod
     def flush(cls, late=False):
-        if not cls.jobs and not cls.held:
+        if not cls.jobs and not cls.held and not (cls.extras and not late):
             return
         jobs, layers, acc = cls.jobs, cls.layers, cls.acc
         cls.jobs, cls.layers, cls.acc = [], [], None
@@ -543,9 +562,19 @@ class DeferredWgrads:
                     region_done(getattr(layer, "_sam_region_id", None))
             cls.late.append(jobs)                 # operands were allocated on the issuing stream: alive until join()
             return
-        ops.wgrad_grouped(jobs, accumulate=acc)
+        if cls.extras and len(jobs) + len(cls.extras) <= 20:
+            jobs, cls.extras = list(jobs) + cls.extras, []
+        if jobs:
+            ops.wgrad_grouped(jobs, accumulate=bool(acc))
         for layer in layers:
             region_done(getattr(layer, "_sam_region_id", None))
+
+    @classmethod
+    def flush_extras(cls):
+        """extras that found no MMT group to ride on (a model whose only group is the late one): launched by themselves, here"""
+        if cls.extras:
+            jobs, cls.extras = cls.extras, []
+            ops.wgrad_grouped(jobs, accumulate=True)
 
     @classmethod
     def join(cls):
@@ -557,13 +586,18 @@ class DeferredWgrads:
     @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
-        cls.held = []
+        cls.held, cls.extras = [], []
         if cls.late:                 # a launch may still be reading its operands on the late stream: the issuing stream waits before they are dropped
             try:
                 torch.cuda.current_stream().wait_stream(cls.late_stream)
             except RuntimeError:
                 pass
         cls.late = []
+
+
+def defer_mmt_pairs_active():
+    """are MMT layers' weight gradients going out in grouped launches at all (modules.SAM4C marks the layers)?"""
+    return os.environ.get("SAM_DEFER_MMT_WGRAD", "2") not in ("0", "1")
 
 
 def wgrad_late_enabled():

@@ -798,10 +798,12 @@ def wgrad_grouped(jobs, force_tile=0, accumulate=True):
     n = len(jobs)
     arr = (capi.GemmDesc * n)()
     flops = 0.0
-    for d, (dy, x, dw, db) in zip(arr, jobs):
+    for d, job in zip(arr, jobs):
+        dy, x, dw, db = job[:4]
+        acc_j = job[4] if len(job) > 4 else accumulate          # (a job may carry its own flag: problems that accumulate next to problems that overwrite)
         d.M, d.N, d.K = dy.shape[1], x.shape[1], dy.shape[0]
         d.a_kcontig = d.b_kcontig = 0
-        d.c_is_f32, d.accumulate, d.epilogue = 1, int(bool(accumulate)), capi.EPI_NONE
+        d.c_is_f32, d.accumulate, d.epilogue = 1, int(bool(acc_j)), capi.EPI_NONE
         d.A, d.lda, d.B, d.ldb, d.C, d.ldc = dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), dw.data_ptr(), dw.stride(0)
         d.bias_grad = _dp(db)
         flops += 2.0 * d.M * d.N * d.K
