@@ -501,7 +501,14 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
 
 }  // namespace
 
+static int grouped_impl(const sam_gemm_desc* descs, int count, void* stream, int ft);
+
 extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream) {
+  SAM_REQUIRE(descs && count >= 1 && count <= SAM_MAX_GROUP8, "sam_gemm_bf16_grouped: 1..%d problems", SAM_MAX_GROUP8);
+  return grouped_impl(descs, count, stream, descs[0].force_tile);
+}
+
+static int grouped_impl(const sam_gemm_desc* descs, int count, void* stream, const int ft) {
   SAM_REQUIRE(descs && count >= 1 && count <= SAM_MAX_GROUP8, "sam_gemm_bf16_grouped: 1..%d problems", SAM_MAX_GROUP8);
   GroupArgs g = {};             // (the 4-wave kernel's arguments: up to SAM_MAX_GROUP problems; larger sets exist for the 8-wave kernel only)
   g.count = count;
@@ -540,7 +547,6 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
   {
     static int use8 = -1;
     if (use8 < 0) { const char* e = getenv("SAM_GEMM8W"); use8 = e ? atoi(e) : 1; }
-    const int ft = descs[0].force_tile;
     SAM_REQUIRE(ft == 0 || ft == 128 || ft == 1256, "sam_gemm_bf16_grouped: force_tile must be 0, 128 or 1256");
     if ((use8 && ft == 0) || ft == 1256) {
       const int rc = gemm8w_grouped(descs, count, (hipStream_t)stream);
@@ -548,7 +554,17 @@ extern "C" int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void
       SAM_REQUIRE(rc == SAM_ERR_UNSUPPORTED && ft != 1256, "sam_gemm_bf16_grouped: the 8-wave grouped kernel cannot run this problem set (K %% 64, workspace, tile count)");
     }
   }
-  SAM_REQUIRE(count <= SAM_MAX_GROUP, "sam_gemm_bf16_grouped: more than %d problems need the 8-wave kernel, which declined this set", SAM_MAX_GROUP);
+  if (count > SAM_MAX_GROUP) {
+    // sets of 13..SAM_MAX_GROUP8 problems exist for the 8-wave kernel; when it declines one (a K that is not a multiple of 64: batch sizes other than
+    // multiples of 32 / the last partial batch of an epoch; a tile count outside its limits: a GPU with fewer CUs) the set goes out as consecutive
+    // chunks of at most SAM_MAX_GROUP problems, each of which may still take the 8-wave kernel by itself and has the 4-wave kernel below it.
+    // Whether a call succeeds never depends on the device's CU count or on K % 64.
+    for (int q0 = 0; q0 < count; q0 += SAM_MAX_GROUP) {
+      const int rc = grouped_impl(descs + q0, count - q0 < SAM_MAX_GROUP ? count - q0 : SAM_MAX_GROUP, stream, ft);
+      if (rc != SAM_OK) return rc;
+    }
+    return SAM_OK;
+  }
   static bool once = false;
   if (!once) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_group_kernel<128, 128, 2, 2, false, false, SAM_EPI_NONE, float>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * BK * 2);

@@ -543,8 +543,11 @@ class DecodeSession:
                     self._step()
         cur.wait_stream(st)
         torch.cuda.synchronize()
+        from . import parallel
+        parallel.quiesce_before_capture()        # (a live RCCL process group's watchdog must not poll into the capture: parallel.py)
+        mode = parallel.CAPTURE_ERROR_MODE
         g1 = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g1, stream=st):
+        with torch.cuda.graph(g1, stream=st, capture_error_mode=mode):
             self._first()
         self.pool = g1.pool()
         g2 = torch.cuda.CUDAGraph()
@@ -552,11 +555,11 @@ class DecodeSession:
         if self.incremental:                     # one graph per position: its row offsets are by-value arguments
             for t in range(1, self.steps):
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, stream=st):
+                with torch.cuda.graph(g, pool=self.pool, stream=st, capture_error_mode=mode):
                     self._step_inc(t)
                 self.graph_steps.append(g)
         elif self.steps > 1:
-            with torch.cuda.graph(g2, pool=self.pool, stream=st):
+            with torch.cuda.graph(g2, pool=self.pool, stream=st, capture_error_mode=mode):
                 self._steps_fused() if self.fused else self._step()
         self.graph_first, self.graph_step = g1, g2
 

@@ -17,8 +17,45 @@ is the LAST gradient of the backward pass (nothing left to hide its exchange beh
 the reducer leaves it out of the dense buckets (`dense_lo`); instead every rank all-gathers the (row index, bf16 gradient row) pairs
 (2 MB per rank) and scatters all ranks' rows into its own table gradient: same sum, 1/4 less all-reduce volume, and the exposed tail of the
 exchange shrinks from 258 MB to 164 MB."""
+import os
+import time
+
 import torch
 import torch.distributed as dist
+
+from . import rccl
+
+CAPTURE_ERROR_MODE = "thread_local"
+
+
+def quiesce_before_capture():
+    """call before a stream capture is opened in a process that holds an RCCL process group.
+    ProcessGroupNCCL's watchdog thread polls the end events of its outstanding Work objects (hipEventQuery, every 100 ms).  On this HIP runtime such a
+    query from another thread (a) always fails under a GLOBAL-mode capture and (b) in every mode fails with hipErrorCapturedEvent when the stream the event
+    was last recorded on is capturing now; either one invalidates the capture and the watchdog answers with std::terminate (rccl.py; round-4 driver record).
+    The package therefore (1) captures in thread-local mode (CAPTURE_ERROR_MODE), (2) keeps its own collectives off the process-group API (rccl.py: no Work
+    objects on the step's path) and (3) here lets the watchdog retire what rendezvous-time / bench-bracket collectives left behind: everything on the device
+    completes, then the watchdog gets a few of its polling periods."""
+    if not (dist.is_initialized() and torch.cuda.is_available()):
+        return
+    try:
+        if dist.get_backend() != "nccl":
+            return
+    except Exception:
+        return
+    torch.cuda.synchronize()
+    time.sleep(float(os.environ.get("SAM_CAPTURE_QUIESCE_S", "0.35")))
+
+
+def agree(ok, group=None):
+    """True iff `ok` holds on EVERY rank (a capture that failed on one rank must send all ranks down the eager path: half the ranks replaying a graph
+    while the others enqueue the step's collectives one by one would deadlock).  Host-visible, through the process group, outside any capture."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return bool(ok)
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
 
 
 class GradReducer:
@@ -28,7 +65,7 @@ class GradReducer:
         # all-to-all of bf16 slices (rank j receives slice j of every rank: on xGMI's fully connected point-to-point links every pair carries
         # 1/W of the bucket at the same time), fp32 sum of the W slices on receipt, all-gather of the bf16-rounded sums.  Every rank ends
         # with the same bits (each slice is summed by exactly one rank), the sum itself is rounded to bf16 once.
-        self.payload = payload or __import__("os").environ.get("SAM_GRAD_PAYLOAD", "fp32")
+        self.payload = payload or os.environ.get("SAM_GRAD_PAYLOAD", "fp32")
         if self.payload not in ("fp32", "bf16"):
             raise ValueError("GradReducer payload must be 'fp32' or 'bf16', not %r" % (self.payload,))
         self.scatter_fn = scatter_fn or _scatter_rows
@@ -41,17 +78,36 @@ class GradReducer:
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         # SAM_FORCE_DIST=1: run the collectives even in a 1-rank group (exercises the RCCL / side-stream path on a single GPU)
-        self.force = dist.is_initialized() and __import__("os").environ.get("SAM_FORCE_DIST") == "1"
+        self.force = dist.is_initialized() and os.environ.get("SAM_FORCE_DIST") == "1"
         self.per_bucket = max(1, bucket_bytes // flat_grad.element_size())
         self._build_buckets(cut=None)
         # SAM_REDUCER_CHECK=1 (1-rank groups only, where the all-reduce is the identity): keep a copy of every bucket as it is released and
         # verify at finish() that nothing wrote into it afterwards -- catches a premature release on a single GPU
-        self.check = __import__("os").environ.get("SAM_REDUCER_CHECK") == "1" and self.world_size == 1
+        self.check = os.environ.get("SAM_REDUCER_CHECK") == "1" and self.world_size == 1
         self.overlap = overlap and flat_grad.is_cuda and (self.world_size > 1 or self.force)
         self.stream = torch.cuda.Stream() if self.overlap else None
         self.regions = []
         self.barrier_names, self.barrier_regions = set(), []
+        self.comm = self._resolve_comm()
         self.begin_step()
+
+    def _resolve_comm(self):
+        """the group's ncclComm_t when the group is an RCCL group: the collectives are then enqueued directly on the reducer's stream (rccl.py) -- no
+        ProcessGroupNCCL Work objects, no watchdog polling of the step's events.  None: gloo (tests), SAM_RCCL_DIRECT=0, a 1-rank job without a group."""
+        if not (self.grad.is_cuda and dist.is_initialized() and (self.world_size > 1 or self.force)):
+            return None
+        comm = rccl.communicator(self.group)
+        try:
+            is_rccl = dist.get_backend(self.group) == "nccl" and os.environ.get("SAM_RCCL_DIRECT", "1") != "0"
+        except Exception:
+            is_rccl = False
+        if comm is None and is_rccl:
+            # the communicator is built lazily by the group's first collective: make it happen (every rank constructs its reducer at the same point)
+            t = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
+            dist.all_reduce(t, group=self.group)
+            torch.cuda.synchronize()
+            comm = rccl.communicator(self.group)
+        return comm
 
     def _build_buckets(self, cut):
         """buckets walk the dense ranges [sparse_hi, n) and [0, sparse_lo) from the end (ascending index = descending addresses = backward
@@ -160,6 +216,9 @@ class GradReducer:
     def _exchange(self, chunk, async_op):
         """sum `chunk` over the ranks, in place"""
         if self.payload == "fp32":
+            if self.comm is not None:
+                rccl.all_reduce(self.comm, chunk)                      # on the current stream: the reducer's own under overlap, the step's otherwise
+                return
             w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
                 self.work.append(w)
@@ -169,12 +228,44 @@ class GradReducer:
         send = torch.zeros((W * per,), dtype=torch.bfloat16, device=chunk.device)
         send[:n] = chunk                                               # fp32 -> bf16 (RNE), zero tail
         recv = torch.empty_like(send)
-        dist.all_to_all_single(recv, send, group=self.group)           # recv[r * per : (r + 1) * per] = rank r's copy of MY slice
+        if self.comm is not None:
+            rccl.all_to_all(self.comm, recv, send, W)
+        else:
+            dist.all_to_all_single(recv, send, group=self.group)       # recv[r * per : (r + 1) * per] = rank r's copy of MY slice
         mine = recv.view(W, per).float().sum(dim=0).to(torch.bfloat16)  # fp32 accumulation over the ranks, in rank order
         out = torch.empty_like(send)
-        dist.all_gather_into_tensor(out, mine, group=self.group)
+        self._all_gather(out, mine)
         chunk.copy_(out[:n])
         self._keep.append((send, recv, mine, out))                     # (allocated on the caller's stream, used on the reducer's: held until finish())
+
+    def _all_gather(self, out, t):
+        if self.comm is not None:
+            rccl.all_gather(self.comm, out, t)
+        else:
+            dist.all_gather_into_tensor(out, t, group=self.group)
+
+    def reduce_scalar(self, t):
+        """t (a small device tensor) := its sum over the ranks, started now and running underneath whatever the caller enqueues next; returns wait(): call
+        it on the stream that is about to read t.  (The loss normaliser: the count of unmasked decoding steps of the GLOBAL batch, Trainer._eager_step.)"""
+        if self.comm is None:
+            return dist.all_reduce(t, group=self.group, async_op=True).wait
+        if not self.overlap:
+            rccl.all_reduce(self.comm, t)
+            return lambda: None
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            rccl.all_reduce(self.comm, t)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        return lambda: torch.cuda.current_stream().wait_event(ev)
+
+    def broadcast(self, t, src=0):
+        """rank `src`'s t to every rank, complete on return (start-up: masters and optimizer state)"""
+        if self.comm is not None:
+            rccl.broadcast(self.comm, t.view(-1) if t.is_contiguous() else t, src)
+            torch.cuda.synchronize()
+        else:
+            dist.broadcast(t, src=src, group=self.group)
 
     def region_done(self, lo):
         """everything at flat offsets >= lo has its final gradient: launch every bucket that is now complete"""
@@ -191,7 +282,10 @@ class GradReducer:
             if self._checked_rows < 0:                  # all_gather_into_tensor needs the same row count on every rank: verified, loudly, on
                                                         # the first call (every rank makes it: no rank can skip the collective)
                 cnt = torch.tensor([ids.numel(), -ids.numel()], dtype=torch.int64, device=ids.device)
-                dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
+                if self.comm is not None:
+                    rccl.all_reduce(self.comm, cnt, op=rccl.MAX)
+                else:
+                    dist.all_reduce(cnt, op=dist.ReduceOp.MAX, group=self.group)
                 if int(cnt[0]) != -int(cnt[1]):
                     raise RuntimeError("GradReducer.sparse_rows: ranks hold different numbers of rows (%d..%d); pad the last batch" % (-int(cnt[1]), int(cnt[0])))
                 self._checked_rows = ids.numel()
@@ -213,13 +307,13 @@ class GradReducer:
                 self._note_stream()
                 self.stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.stream):
-                    dist.all_gather_into_tensor(ids_all, ids, group=self.group)
-                    dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+                    self._all_gather(ids_all, ids)
+                    self._all_gather(rows_all, rows)
                     self.scatter_fn(grad_table, ids_all, rows_all, padding_idx)
                 self._keep.append((ids, rows, ids_all, rows_all))
                 return
-            dist.all_gather_into_tensor(ids_all, ids, group=self.group)
-            dist.all_gather_into_tensor(rows_all, rows, group=self.group)
+            self._all_gather(ids_all, ids)
+            self._all_gather(rows_all, rows)
             ids, rows = ids_all, rows_all
         self.scatter_fn(grad_table, ids, rows, padding_idx)
 
@@ -257,7 +351,6 @@ active_reducer = None   # set by the Trainer; EncoderLayerFn.backward reports fi
 
 def init_distributed():
     """read RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment (torch.distributed.run contract)"""
-    import os
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

@@ -53,7 +53,7 @@ class Trainer:
             # replicas must START identical and nothing re-synchronises them later: rank 0's masters and optimizer state go to everyone
             # (this also creates the RCCL communicator here, not inside the first timed step)
             for buf in (self.flat.flat, self.exp_avg, self.exp_avg_sq):
-                dist.broadcast(buf, src=0, group=reducer.group)
+                reducer.broadcast(buf, src=0)
             self.flat.refresh_shadows()
         if reducer is not None:
             self._register_regions(reducer)
@@ -302,18 +302,18 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.begin_step()
         parallel.active_reducer = self.reducer
-        c_global = work = None
+        c_global = wait_count = None
         if self.reducer is not None and parallel.dist.is_initialized():
             # the reference normalises the loss by the number of unmasked decoding steps of the WHOLE batch (nn.DataParallel gathers the
             # scores before the loss, task_utils.py:28-29): every rank contributes its RAW count now (the all-reduce of one float runs
             # underneath the forward pass); the loss kernel divides by max(global count, 1), so the all-reduce SUM of the per-rank gradients
             # is exactly the gradient of the global mean
             c_global = batch_dict["train_loss_mask"].to(device=flat.grad.device, dtype=torch.float32).sum().reshape(1)
-            work = parallel.dist.all_reduce(c_global, group=self.reducer.group, async_op=True)
+            wait_count = self.reducer.reduce_scalar(c_global)
         batch_dict["_sam_want_scores"] = False                   # the loss kernel reads the classifier / pointer blocks separately
         model(batch_dict)
-        if work is not None:
-            work.wait()
+        if wait_count is not None:
+            wait_count()
         loss = masked_bce_loss(batch_dict, 1.0, unit_grad=True, global_count=c_global)
         # the encoder layers' LayerNorm backwards leave their dgamma / dbeta / dbias partial sums in place; ONE launch reduces all of them after the
         # backward pass (26 finalize launches of ~6 us each otherwise).  Under a reducer a layer's gradients must be final when its region is
@@ -443,11 +443,18 @@ class Trainer:
                     loss = self._eager_step(batch_dict)
                 torch.cuda.current_stream().wait_stream(self._cap_stream)
                 return loss
+            err = None
             try:
                 self._capture(items, sig, dev)
             except Exception as e:                               # capture is an optimisation: never lose the run over it
+                err = e
+            # data parallel: the step is replayed on ALL ranks or on none (a rank that replays while another enqueues the collectives one by one would
+            # hang the job): the ranks agree, through the process group, after the capture has closed on every one of them
+            everyone = parallel.agree(err is None, self.reducer.group) if self.reducer is not None else err is None
+            if not everyone:
                 import logging
-                logging.getLogger(__name__).warning("hipGraph capture of the training step failed (%s: %s); continuing eagerly", type(e).__name__, e)
+                logging.getLogger(__name__).warning("hipGraph capture of the training step failed (%s); continuing eagerly",
+                                                    "%s: %s" % (type(err).__name__, err) if err is not None else "on another rank")
                 ops.set_rng_state(None)
                 self._ln_clear()                                 # nothing a half-recorded backward queued may survive into the eager step
                 ops.reset_workspaces()
@@ -517,13 +524,14 @@ class Trainer:
         saved_offset, dropout_clock.offset = dropout_clock.offset, 0          # by-value offsets inside the graph: 1, 2, 3, ... per site
         g = torch.cuda.CUDAGraph()
         torch.cuda.synchronize()
+        parallel.quiesce_before_capture()                      # (RCCL process group alive: its watchdog must hold no outstanding Work when the capture opens)
         ops.set_rng_state(self._rng_state)
         import gc
         gc.collect()                       # (garbage that owns hipGraphs must not be collected in the middle of the capture: decoder.DecodeSession._capture)
         gc_was_enabled = gc.isenabled()
         gc.disable()
         try:
-            with torch.cuda.graph(g, stream=self._cap_stream):
+            with torch.cuda.graph(g, stream=self._cap_stream, capture_error_mode=parallel.CAPTURE_ERROR_MODE):
                 bd = {k: (dict(v) if isinstance(v, dict) else v) for k, v in static_bd.items()}
                 if self._pipelined_graph:
                     loss = self._eager_step(bd, sched_dev=self._sched_dev, pipelined=True)

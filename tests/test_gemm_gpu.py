@@ -379,6 +379,28 @@ def test_grouped_wgrad_mixed_depths_in_one_launch():
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
 
 
+def test_grouped_wgrad_more_than_twelve_problems_the_eight_wave_kernel_declines():
+    """20 problems whose depths are not multiples of 64 (a batch that is not a multiple of 32): the 8-wave grouped kernel declines, the set goes
+    out as chunks of at most 12 on the 4-wave kernel instead of raising (whether the call succeeds must not depend on K % 64 or the CU count); fp32 reference,
+    fused bias gradients, per-job accumulate flags, and the forced 4-wave route (force_tile = 128) the same way"""
+    ops, capi = _mods()
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    for force in (0, 128):
+        deep, deep_ref = _wgrad_jobs(1096, shapes * 2, seed0=300, bias=(0, 3, 5))        # 6 * 182 + 4: K % 64 = 8
+        shal, shal_ref = _wgrad_jobs(120, shapes * 3, seed0=400, bias=(1, 2, 7, 11))     # 6 * 20
+        ops.wgrad_grouped(deep + shal, force_tile=force)
+        for (dy, x, dw, db), (rw, rb) in zip(deep + shal, deep_ref + shal_ref):
+            assert_close_bf16(dw, rw, ulps=0, name="20-problem chunked grouped wgrad")
+            if db is not None:
+                assert_close_bf16(db, rb, ulps=0, name="20-problem chunked grouped bias grad")
+    junk = [(dy, x, torch.full_like(dw, 3.5), None if db is None else torch.full_like(db, -1.0)) for dy, x, dw, db in deep + shal]
+    ops.wgrad_grouped(junk, accumulate=False)
+    zero = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in deep + shal]
+    ops.wgrad_grouped(zero)
+    for a, b in zip(zero, junk):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
+
+
 def test_grouped_wgrad_eight_wave_ragged_and_unsplit():
     """tile edges (M, N multiples of 8 but not of 256), a single problem, and a problem set with too many tiles for pairs (one block per tile)"""
     ops, capi = _mods()

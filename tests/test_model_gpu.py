@@ -320,6 +320,7 @@ print("STRESS_OK")
 """
 
 
+@pytest.mark.transport
 def test_stress_shape_train_step_b32_twelve_layers_with_reducer_check():
     """BASELINE config 5 as the bench runs it: B = 32, 350 tokens (M = 11200 rows), 12 layers, dropout on, the data-parallel reducer active in a
     1-rank RCCL group with SAM_REDUCER_CHECK=1 (every bucket re-verified at finish()); three steps, finite and decreasing loss"""
@@ -329,8 +330,39 @@ def test_stress_shape_train_step_b32_twelve_layers_with_reducer_check():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-c", _STRESS_SCRIPT], env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0 and "STRESS_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    from tests.util import run_child
+    run_child([sys.executable, "-c", _STRESS_SCRIPT], env, "STRESS_OK", "stress_train_step", timeout=900)
+
+
+@pytest.mark.parametrize("batch", [6, 48])
+def test_trainer_full_depth_batches_the_eight_wave_wgrad_declines(batch, monkeypatch):
+    """without a gradient reducer the MMT's last layer pair is held and merged with TextBert's 12 problems into ONE grouped wgrad call of 20.
+    The 8-wave grouped kernel declines a set when a K = B * N is not a multiple of 64 (B = 6: both; B = 48: the MMT's 48 * 182) -- any batch that is not a
+    multiple of 32, e.g. the last partial batch of an epoch (the reference's loader keeps it: sam/task_utils.py:163).  Sets above 12 problems must then
+    go out as chunks the 4-wave kernel takes (csrc/gemm.hip: sam_gemm_bf16_grouped), and train like the unmerged path."""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import clone_batch, make_batch, mmt_config_dict, text_bert_config_dict
+    from sam_textvqa_amd.trainer import Trainer
+    shapes = (20, 100, 50, 12)
+    md = mmt_config_dict(3, ("n", "n", "s", "s"), n_dec=12, T=20, n_obj=100, n_ocr=50)
+    md.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, obj_drop=0.0, ocr_drop=0.0)
+    td = dict(text_bert_config_dict(), num_hidden_layers=3, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=500)
+    data = make_batch(batch, *shapes, vocab=300, device="cuda", seed=5)
+    data["question_indices"] = data["question_indices"] % 500
+    res = []
+    for merge in ("1", "0"):
+        monkeypatch.setenv("SAM_WGRAD_MERGE_TB", merge)
+        torch.manual_seed(0)
+        model = M.SAM4C(M.BertConfig.from_dict(md), M.BertConfig.from_dict(td), num_answers=300, bos_idx=1)
+        tr = Trainer(model, base_lr=1e-3, seed=3)
+        assert tr.reducer is None
+        losses = [tr.step(clone_batch(data)).item() for _ in range(3)]
+        torch.cuda.synchronize()
+        assert all(np.isfinite(losses)), losses
+        res.append((losses, tr.flat.flat.clone()))
+    (l1, p1), (l0, p0) = res
+    assert all(abs(a - b) <= 2e-3 * abs(b) for a, b in zip(l1, l0)), (l1, l0)
+    assert (p1 - p0).abs().max().item() < 5e-3
 
 
 def test_trainer_steps_reduce_loss_and_checkpoint_roundtrip():
@@ -580,6 +612,7 @@ print("DIST_OK")
 """
 
 
+@pytest.mark.transport
 @pytest.mark.parametrize("three_groups", [False, True])
 def test_rccl_path_one_rank_matches_plain_trainer(tmp_path, three_groups):
     """SAM_FORCE_DIST=1: bucketed all-reduce on the side stream + the row-sparse word-embedding exchange run through RCCL in a 1-rank
@@ -592,8 +625,8 @@ def test_rccl_path_one_rank_matches_plain_trainer(tmp_path, three_groups):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                HSA_ENABLE_IPC_MODE_LEGACY="0", SAM_TEST_THREE_GROUPS="1" if three_groups else "0")
-    r = subprocess.run([sys.executable, "-c", _DIST_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0 and "DIST_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    from tests.util import run_child
+    run_child([sys.executable, "-c", _DIST_SCRIPT], env, "DIST_OK", "rccl_one_rank_%s" % ("three_groups" if three_groups else "two_groups"))
 
 
 def test_training_trajectory_matches_oracle_train_step():

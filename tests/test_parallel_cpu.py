@@ -166,3 +166,53 @@ def test_global_loss_normaliser_identity():
     total = counts.sum()
     ddp = sum((c / total) * x.mean(0) for c, x in zip(counts, per_rank))
     assert torch.allclose(ddp, torch.cat(per_rank).mean(0), atol=1e-6)
+
+
+def test_rccl_binding_resolves_every_entry_point_and_declines_without_a_group():
+    """sam_textvqa_amd/rccl.py: the library torch.distributed's "nccl" backend is built on is found among the process's mapped objects (or next to torch), every
+    entry point the reducer calls resolves with the rccl.h signatures, and without an RCCL process group there is no communicator: callers stay on the
+    process-group API (gloo: these CPU tests and the shared-GPU two-rank tests)."""
+    from sam_textvqa_amd import rccl
+    l = rccl.lib()
+    for name in ("ncclAllReduce", "ncclAllGather", "ncclAllToAll", "ncclBroadcast", "ncclCommCount", "ncclGetErrorString"):
+        assert hasattr(l, name), name
+    assert l.ncclGetErrorString(0) == b"no error"
+    assert rccl.communicator() is None
+    assert rccl._DTYPES[torch.float32] == 7 and rccl._DTYPES[torch.bfloat16] == 9 and rccl._DTYPES[torch.int64] == 4 and (rccl.SUM, rccl.MAX) == (0, 2)      # rccl.h enums
+
+
+def _agree_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from sam_textvqa_amd import parallel
+    parallel.init_distributed()
+    red = parallel.GradReducer(torch.zeros(64), bucket_bytes=4 * 16)
+    assert red.comm is None                                   # gloo: the process-group transport
+    t = torch.tensor([float(rank + 1)])
+    wait = red.reduce_scalar(t)                               # the global loss-normaliser count of Trainer._eager_step
+    wait()
+    buf = torch.full((8,), float(rank))
+    red.broadcast(buf, src=1)
+    out = (parallel.agree(True), parallel.agree(rank == 0), parallel.agree(False), float(t.item()), buf.tolist())
+    parallel.quiesce_before_capture()                         # no-op off the RCCL backend
+    q.put((rank,) + out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_capture_agreement_and_scalar_reduce_gloo_world2():
+    """a hipGraph capture that fails on ONE rank must send ALL ranks down the eager path (parallel.agree: MIN over the ranks, host-visible); the reducer's
+    scalar all-reduce and start-up broadcast on the process-group transport"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_agree_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert res == [(0, True, False, False, 3.0, [1.0] * 8), (1, True, False, False, 3.0, [1.0] * 8)]
+    from sam_textvqa_amd import parallel
+    assert parallel.agree(True) is True and parallel.agree(False) is False      # no group: the local answer
+    assert parallel.CAPTURE_ERROR_MODE == "thread_local"

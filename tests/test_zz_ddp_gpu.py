@@ -8,7 +8,7 @@ import pytest
 import torch
 import torch.multiprocessing as mp
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.transport]
 SHAPES = (20, 100, 50, 12)
 STEPS = 4
 
@@ -152,8 +152,8 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline"]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=root)
-    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    from tests.util import run_child
+    r = run_child(cmd, env, None, "bench_dist_run_one_rank_%s" % payload, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -208,5 +208,5 @@ def test_data_parallel_step_is_captured_and_trains_like_the_plain_step():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("SAM_REDUCER_CHECK", None)
-    r = subprocess.run([sys.executable, "-c", _GRAPH_DP_SCRIPT], env=env, capture_output=True, text=True, timeout=600, cwd=root)
-    assert r.returncode == 0 and "GRAPH_DP_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+    from tests.util import run_child
+    run_child([sys.executable, "-c", _GRAPH_DP_SCRIPT], env, "GRAPH_DP_OK", "graph_dp_step")

@@ -26,3 +26,33 @@ def assert_close_bf16(got, ref, frac=1e-3, ulps=1, name=""):
     worst = (err - bound).max().item()
     assert worst <= 0, "%s: max err %.4g (scale %.4g) exceeds bound by %.4g" % (name, err.max().item(), ref.abs().max().item(), worst)
     return err.max().item() / max(ref.abs().max().item(), 1e-30)
+
+
+def run_child(cmd, env, marker, name, timeout=600, cwd=None):
+    """run a child process (a data-parallel rank, bench.py under torch.distributed.run, ...), keep its FULL stdout / stderr on disk and fail with the path
+    and a long tail: pytest's assertion repr cuts captured text to a few hundred characters, which in round 4 hid the one line that named the cause
+    (`Process group watchdog thread terminated with exception: ...`).  Files: <repo>/gpurun_out/test_children/<name>.{stdout,stderr} (gpurun merges that
+    directory back), returns the CompletedProcess."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out_dir = os.path.join(root, "gpurun_out", "test_children")
+    os.makedirs(out_dir, exist_ok=True)
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd or root)
+        rc, so, se = r.returncode, r.stdout, r.stderr
+    except subprocess.TimeoutExpired as e:
+        dec = lambda b: b.decode("utf-8", "replace") if isinstance(b, bytes) else (b or "")
+        r, rc, so, se = None, "timeout after %ds" % timeout, dec(e.stdout), dec(e.stderr)
+    paths = []
+    for ext, text in (("stdout", so), ("stderr", se)):
+        path = os.path.join(out_dir, "%s.%s" % (name, ext))
+        with open(path, "w") as f:
+            f.write(text)
+        paths.append(path)
+    if rc != 0 or (marker and marker not in so):
+        import sys
+        print("child %s: rc %s; full output in %s" % (name, rc, paths), file=sys.stderr)
+        raise AssertionError("child %s ended with rc %s%s; full output: %s\n---- stdout tail ----\n%s\n---- stderr tail ----\n%s"
+                             % (name, rc, "" if not marker or marker in so else " without printing %r" % marker, paths, so[-3000:], se[-8000:]))
+    return r
