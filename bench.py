@@ -543,6 +543,9 @@ def main():
         res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
         res["overlap"] = bool(trainer.reducer.overlap)
         res["grad_payload"] = trainer.reducer.payload
+        # "rccl-direct": ncclAllReduce / ncclAllGather enqueued by the reducer itself on its stream over the group's communicator (sam_textvqa_amd/rccl.py);
+        # "process-group": torch.distributed calls (gloo, or SAM_RCCL_DIRECT=0)
+        res["dp_transport"] = "rccl-direct" if trainer.reducer.comm is not None else "process-group"
     res["step_mode"] = "hipGraph replay" if (trainer.use_graph and trainer._graph is not None) else "eager launches"
     if trainer.reducer is not None and trainer._graph is not None:
         # the exchange is inside the captured step, where no timing event can sit: the exposed part is measured on a few eager steps of the same trainer

@@ -128,13 +128,25 @@ __global__ __launch_bounds__(256) void embed_sum_bwd_kernel(const bf16_t* d, int
 #pragma unroll
   for (int t = 0; t < EMBED_MAX_TYPES; ++t) acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0.f;
   if (live)
-    for (int r = s + ry * S; r < R; r += 4 * S) {
-      const int t = type_ids ? type_ids[r] : 0;
-      float v[4];
-      ld4bf(d + (int64_t)r * ldd + 4 * c4, v);
+    for (int r0 = s + ry * S; r0 < R; r0 += 16 * S) {
+      // four rows per trip, all eight loads issued before the first add (a trip per row was 16 dependent HBM / L2 round trips per thread on a 60-block
+      // grid: 30 us on the tail's chain for 2 MB); the rows are still added in ascending order
+      int tt[4];
+      float v[4][4];
 #pragma unroll
-      for (int u = 0; u < EMBED_MAX_TYPES; ++u)
-        if (t == u) { acc[u][0] += v[0]; acc[u][1] += v[1]; acc[u][2] += v[2]; acc[u][3] += v[3]; }
+      for (int k = 0; k < 4; ++k) {
+        const int r = r0 + 4 * S * k;
+        tt[k] = -1;
+        if (r < R) {
+          tt[k] = type_ids ? type_ids[r] : 0;
+          ld4bf(d + (int64_t)r * ldd + 4 * c4, v[k]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int u = 0; u < EMBED_MAX_TYPES; ++u)
+          if (tt[k] == u) { acc[u][0] += v[k][0]; acc[u][1] += v[k][1]; acc[u][2] += v[k][2]; acc[u][3] += v[k][3]; }
     }
 #pragma unroll
   for (int t = 0; t < EMBED_MAX_TYPES; ++t)
@@ -162,7 +174,14 @@ __global__ __launch_bounds__(256) void embed_type_finalize_kernel(const float* w
   const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
   if (c >= D) return;
   float a = 0.f;
-  for (int s = 0; s < S; ++s) a += ws[((int64_t)s * n_types + t) * D + c];
+  for (int s0 = 0; s0 < S; s0 += 8) {          // eight partials requested at a time, added in the same order
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = s0 + k < S ? ws[((int64_t)(s0 + k) * n_types + t) * D + c] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (s0 + k < S) a += v[k];
+  }
   d_tt[(int64_t)t * ld_tt + c] += a;
 }
 

@@ -36,10 +36,16 @@ __device__ __forceinline__ void tile_origin(const GemmArgs& p, int id, int& m0, 
   n0 = (in_group / gsize) * BN;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT>
+template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST = 2>
 __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_kernel(GemmArgs p) {
   constexpr int TM = BM / 32, TN = BN / 64, SA = BM / 64, SB = BN / 64, RB = TM / 2;
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+  // LDS stages.  Two everywhere but the 192 x 192 tile, whose 48 KB stages fit THREE times: A is then fetched two k-tiles ahead and B three (one / two with two
+  // stages).  The issue points do not move (phase 0 / phase 1 read segments); what changes is the distance between a DMA's issue and the wait that needs it:
+  // with COLD operands (a training step never finds an activation in the Infinity Cache) one k-tile -- ~1.1 us -- is less than the HBM round trip under load, and
+  // the long-K N = 768 products (FFN2 forward, FFN1 / QKV dgrad: A is 72 / 54 MB streamed once, 128 bytes per row and k-tile) stalled ~10 us of their 60 in
+  // that wait (SAM_GEMM8_DBG = 1 / 9 / 5: loop only 61.1 us, with every DMA re-reading an L2-resident k-tile 49.7, without DMA 40.4).
+  static_assert(NST == 2 || NST == 3, "two or three LDS stages");
   static_assert(BM % 64 == 0 && BN % 64 == 0 && SB <= 4, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, g = lane >> 4;
@@ -56,26 +62,27 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_ker
   tile_origin<BM, BN>(p, blockIdx.x, m0, n0);
   src_offsets<AKC, SA>(offA, p.lda, m0, p.M, wave, lane);
   src_offsets<BKC, SB>(offB, p.ldb, n0, p.N, wave, lane);
-  int ua = 0, ka = 0, ja = 0, ub = 0, kb = 0, jb = 0;
+  int ua = 0, ka = 0, ja = 0, ub = 0, kb = 0, jb = 0, sa_ = 0, sb_ = 0;       // sa_ / sb_: LDS stage of the next A / B fetch (= ua % NST, ub % NST)
   (void)ma; (void)na_; (void)mb_; (void)nb;
 #define SAM_DMA_A()                                                                                                     \
   do {                                                                                                                  \
-    dma_slices<SA>(p.A, smem + (ua & 1) * STAGE + wave * (SA * 1024), offA, ka * kstepA);                               \
-    ++ua;                                                                                                               \
+    dma_slices<SA>(p.A, smem + sa_ * STAGE + wave * (SA * 1024), offA, (p.dbg & 8) ? 0u : ka * kstepA);            \
+    ++ua; sa_ = sa_ + 1 == NST ? 0 : sa_ + 1;                                                                           \
     if (++ka == KT) {                                                                                                   \
       ka = 0; ++ja;                                                                                                     \
-      if (ja < my_tiles) { tile_origin<BM, BN>(p, blockIdx.x + ja * G, ma, na_); src_offsets<AKC, SA>(offA, p.lda, ma, p.M, wave, lane); } \
+      if (ja < my_tiles && !(p.dbg & 8)) { tile_origin<BM, BN>(p, blockIdx.x + ja * G, ma, na_); src_offsets<AKC, SA>(offA, p.lda, ma, p.M, wave, lane); } \
     }                                                                                                                   \
   } while (0)
 #define SAM_DMA_B()                                                                                                     \
   do {                                                                                                                  \
-    dma_slices<SB>(p.B, smem + (ub & 1) * STAGE + A_BYTES + wave * (SB * 1024), offB, kb * kstepB);                     \
-    ++ub;                                                                                                               \
+    dma_slices<SB>(p.B, smem + sb_ * STAGE + A_BYTES + wave * (SB * 1024), offB, (p.dbg & 8) ? 0u : kb * kstepB);  \
+    ++ub; sb_ = sb_ + 1 == NST ? 0 : sb_ + 1;                                                                           \
     if (++kb == KT) {                                                                                                   \
       kb = 0; ++jb;                                                                                                     \
-      if (jb < my_tiles) { tile_origin<BM, BN>(p, blockIdx.x + jb * G, mb_, nb); src_offsets<BKC, SB>(offB, p.ldb, nb, p.N, wave, lane); } \
+      if (jb < my_tiles && !(p.dbg & 8)) { tile_origin<BM, BN>(p, blockIdx.x + jb * G, mb_, nb); src_offsets<BKC, SB>(offB, p.ldb, nb, p.N, wave, lane); } \
     }                                                                                                                   \
   } while (0)
+  // (dbg bit 3, tuning: every DMA re-reads k-tile 0 of the block's first tile -- L2-resident after the first touch: the issue + LDS-write cost without the HBM wait)
 
   f32x4 acc[TN][TM];
 #pragma unroll
@@ -83,20 +90,28 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_ker
 #pragma unroll
     for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // prologue: k-tile 0 complete, B of k-tile 1 in flight
+  // prologue: k-tile 0 complete; in flight behind it B(1) [two stages] or A(1), B(1), B(2) [three]
   SAM_DMA_A(); SAM_DMA_B();
-  if (total > 1) { SAM_DMA_B(); vmwait<SB>(); }
-  else vmwait<0>();
+  if constexpr (NST == 2) {
+    if (total > 1) { SAM_DMA_B(); vmwait<SB>(); }
+    else vmwait<0>();
+  } else {
+    if (total > 2) { SAM_DMA_A(); SAM_DMA_B(); SAM_DMA_B(); vmwait<SA + 2 * SB>(); }
+    else if (total > 1) { SAM_DMA_A(); SAM_DMA_B(); vmwait<SA + SB>(); }
+    else vmwait<0>();
+  }
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();      // lower row group: one barrier behind from here on
 
   const int sig = ((i >> 3) & 1) | ((g & 1) << 1);     // sigma(krow) for krow = 32 ks + 8 g + (i >> 2)
   bf16x8 af[RB][2], bfr[TN][2];
   int kt = 0, j = 0;
+  int su = 0;                                        // stage of k-tile u
   for (int u = 0; u < total; ++u) {
-    const unsigned char* stA = smem + (u & 1) * STAGE;
+    const unsigned char* stA = smem + su * STAGE;
     const unsigned char* stB = stA + A_BYTES;
-    // ================= phase 0: all B fragments + upper A rows; DMA of A(u+1) (its stage was last read in phase 1 of k-tile u-1)
+    su = su + 1 == NST ? 0 : su + 1;
+    // ================= phase 0: all B fragments + upper A rows; DMA of A(u+1) [A(u+2) with three stages] (its stage was last read in phase 1 of k-tile u-1)
 #pragma unroll
     for (int x = 0; x < TN; ++x)
 #pragma unroll
@@ -105,7 +120,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_ker
     for (int x = 0; x < RB; ++x)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<AKC>(stA, wr * (BM / 2) + x * 16, ks, i, g, sig);
-    if (ua < total) SAM_DMA_A();
+    if (ua < total && !(p.dbg & 4)) SAM_DMA_A();           // (dbg bit 2, tuning: no operand DMA inside the loop -- stale operands, wrong results: what does the DMA issue cost the loop?)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // before the barrier: when the partner group passes it, this stage's B region may be refilled
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -124,8 +139,15 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_ker
     for (int x = 0; x < RB; ++x)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<AKC>(stA, wr * (BM / 2) + (RB + x) * 16, ks, i, g, sig);
-    if (ub < total) { SAM_DMA_B(); vmwait<SB>(); }          // k-tile u+1 has landed (loads retire in order); B(u+2) stays in flight
-    else vmwait<0>();
+    if constexpr (NST == 2) {
+      if (ub < total && !(p.dbg & 4)) { SAM_DMA_B(); vmwait<SB>(); }          // k-tile u+1 has landed (loads retire in order); B(u+2) stays in flight
+      else vmwait<0>();
+    } else {
+      // three stages: B(u+3) goes out; A(u+1) and everything older must have landed, i.e. what may stay in flight is exactly what was issued after A(u+1):
+      // B(u+2), A(u+2), B(u+3).  A count that is too large is a race, so the last three k-tiles of the block's stream simply drain.
+      if (ub < total && !(p.dbg & 4)) { SAM_DMA_B(); vmwait<SA + 2 * SB>(); }
+      else vmwait<0>();
+    }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -145,7 +167,7 @@ __global__ __launch_bounds__(512, (BM * BN <= 128 * 128 ? 4 : 2)) void gemm8_ker
       // be covered by one 18-MFMA phase of the partner: two serial epilogues per tile); the lower group drops back behind afterwards.
       if (wr == 0) __builtin_amdgcn_s_barrier();
       const bool full = m0 + BM <= p.M && n0 + BN <= p.N;
-      if (p.dbg == 1) {        // experiment: how long does the tile stream take without any epilogue?  (one dummy store keeps the accumulators live)
+      if (p.dbg & 1) {        // experiment: how long does the tile stream take without any epilogue?  (one dummy store keeps the accumulators live)
         float sacc = 0.f;
 #pragma unroll
         for (int a = 0; a < TN; ++a)
@@ -478,18 +500,19 @@ int launch8d(GemmArgs a, int n_cu, hipStream_t st) {
   return SAM_OK;
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT>
+template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST = 2>
 int launch8(GemmArgs a, int n_cu, hipStream_t st) {
-  constexpr size_t LDS = (size_t)2 * (BM + BN) * 128;
+  constexpr size_t LDS = (size_t)NST * (BM + BN) * 128;
+  static_assert(LDS <= 160 * 1024, "LDS stages");
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     once = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int tiles = a.tiles_m * a.tiles_n;
   const int slots = BM * BN <= 128 * 128 ? 2 * n_cu : n_cu;      // the 128 x 128 configuration (64 KB of stages, <= 128 VGPRs) runs two blocks per CU
-  gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT><<<dim3(tiles < slots ? tiles : slots), dim3(512), LDS, st>>>(a);
+  gemm8_kernel<BM, BN, AKC, BKC, EPI, OutT, NST><<<dim3(tiles < slots ? tiles : slots), dim3(512), LDS, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -532,7 +555,10 @@ int pick8(const GemmArgs& a, int tile, hipStream_t st) {
     if constexpr (std::is_same<OutT, bf16_t>::value) {
       if ((defer || tile == 3192) && tile != 2192 && a.N <= 4096 && a.M * (int64_t)(EPI == SAM_EPI_BIAS_DROPOUT_RES ? a.ldr : a.ld_aux) * 2 < (int64_t)0x7fffffff) return launch8d<AKC, BKC, EPI>(a, n_cu, st);
     }
-    return launch8<192, 192, AKC, BKC, EPI, OutT>(a, n_cu, st);
+    static int stages = -1;
+    if (stages < 0) { const char* v = getenv("SAM_GEMM8_STAGES"); stages = v ? atoi(v) : 3; }      // (2: the two-stage ring of rounds 2-4, for an A/B)
+    if (stages == 2) return launch8<192, 192, AKC, BKC, EPI, OutT, 2>(a, n_cu, st);
+    return launch8<192, 192, AKC, BKC, EPI, OutT, 3>(a, n_cu, st);
   }
   return SAM_ERR_UNSUPPORTED;
 }

@@ -38,12 +38,8 @@ __device__ __forceinline__ void dma_slices(const bf16_t* base, unsigned char* ds
 }
 template <int N>
 __device__ __forceinline__ void vmwait() {
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else static_assert(N <= 4, "vmwait");
+  static_assert(N >= 0 && N <= 63, "vmwait: vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 // 16 rows x 32 k fragment for lane (i, g): k = 32 ks + 8 g + e in both storage kinds
 template <bool KC>

@@ -113,8 +113,9 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
   src_offsets<false, SB>(offB, P.ldb, n0, P.N, wave, lane);
   const unsigned kstepA = (unsigned)(BK * P.lda * 2), kstepB = (unsigned)(BK * P.ldb * 2);
   int ua = 0, ub = 0;
-#define SAM_DMA_A() do { dma_slices<SA>(P.A, smem + (ua & 1) * STAGE + wave * (SA * 1024), offA, (kt0 + ua) * kstepA); ++ua; } while (0)
-#define SAM_DMA_B() do { dma_slices<SB>(P.B, smem + (ub & 1) * STAGE + A_BYTES + wave * (SB * 1024), offB, (kt0 + ub) * kstepB); ++ub; } while (0)
+  // (dbg bit 3, tuning: every DMA re-reads the tile's first k-tile -- L2-resident: the loop without the HBM wait; bit 2: no DMA inside the loop at all)
+#define SAM_DMA_A() do { dma_slices<SA>(P.A, smem + (ua & 1) * STAGE + wave * (SA * 1024), offA, (w.dbg & 8) ? 0u : (kt0 + ua) * kstepA); ++ua; } while (0)
+#define SAM_DMA_B() do { dma_slices<SB>(P.B, smem + (ub & 1) * STAGE + A_BYTES + wave * (SB * 1024), offB, (w.dbg & 8) ? 0u : (kt0 + ub) * kstepB); ++ub; } while (0)
 
   f32x4 acc[TN][TM], accb = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
     for (int x = 0; x < RB; ++x)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<false>(stA, wr * (BM / 2) + x * 16, ks, i, g, sig);
-    if (ua < total) SAM_DMA_A();
+    if (ua < total && !(w.dbg & 4)) SAM_DMA_A();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
     for (int x = 0; x < RB; ++x)
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<false>(stA, wr * (BM / 2) + (RB + x) * 16, ks, i, g, sig);
-    if (ub < total) { SAM_DMA_B(); vmwait<SB>(); }
+    if (ub < total && !(w.dbg & 4)) { SAM_DMA_B(); vmwait<SB>(); }
     else vmwait<0>();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void gemm8w_kernel(WArgs w) {
 #undef SAM_DMA_A
 #undef SAM_DMA_B
 
-  if (w.dbg == 1) return;                          // (tuning: the k loop alone)
+  if (w.dbg & 1) return;                           // (tuning: the k loop alone)
   // ---- bias partials of the four waves sharing a row range -> one vector per row half in LDS: bsum[wr * 128 + row]
   float* bsum = reinterpret_cast<float*>(smem);            // (the operand stages are dead)
   if (do_bias) {

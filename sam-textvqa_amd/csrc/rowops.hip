@@ -8,6 +8,7 @@
 //   ptr scores         <- OcrPtrNet.forward bilinear + additive mask, sam/sa_m4c.py:878-897
 //   adam / sumsq       <- clip_grad_norm_ + Adam step of train.py:139-142 over one flat parameter buffer
 #include "common.h"
+#include <stdlib.h>
 #include "sam_hip.h"
 
 namespace {
@@ -639,6 +640,48 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const bf16_t* dy, in
   }
 }
 
+// the default: no atomics, no sort.  The block of the FIRST occurrence of a table row is the row's only writer: it adds its own dy row and every later
+// duplicate's, in list order (fixed summation order: run-to-run and -- the data-parallel scatter hands every rank the same gathered list -- rank-to-rank
+// bit-identical).  Finding the duplicates is a scan of the index list: 256 indices per step and thread group, T / 256 steps (T = 1280 tokens per rank).
+// Why not the atomics above: device-scope fp32 atomics do not execute in the (per-XCD, mutually incoherent) L2s but at the memory side of the fabric --
+// 983 k of them for 1280 rows took 89 us inside the replayed step (200 us queued behind other work), all of it on the tail's critical chain.
+__global__ __launch_bounds__(256) void embedding_bwd_dedup_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
+                                                                  unsigned char* touched) {
+  const int t = blockIdx.x, tid = threadIdx.x;
+  const int64_t row = idx[t];
+  if (row < 0 || row >= rows || row == padding_idx) return;
+  int dup = 0;
+  for (int s = tid; s < t; s += 256) dup |= idx[s] == row;
+  if (__syncthreads_or(dup)) return;                      // an earlier block owns this row
+  if (touched && tid == 0) touched[row] = 1;
+  const int nch = (D / 4 + 255) / 256;                    // float4 chunks per thread (D = 768: one, on 192 of the 256 threads)
+  for (int cc = 0; cc < nch; ++cc) {
+    const int c = tid + 256 * cc;
+    const bool live = c * 4 < D;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (live) Ld4<bf16_t>::ld(dy, (int64_t)t * ldd + 4 * c, a);
+    for (int base = t + 1; base < T; base += 256) {
+      const int s = base + tid;
+      const int hit = s < T && idx[s] == row;
+      if (__syncthreads_or(hit)) {                        // rare: a duplicate among these 256 positions -- walk them in order (block-uniform loop)
+        const int end = min(base + 256, T);
+        for (int k = base; k < end; ++k)
+          if (idx[k] == row && live) {
+            float v[4];
+            Ld4<bf16_t>::ld(dy, (int64_t)k * ldd + 4 * c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+          }
+      }
+    }
+    if (live) {
+      float4* g = reinterpret_cast<float4*>(grad + row * ldg + 4 * c);
+      const float4 o = *g;
+      *g = make_float4(o.x + a[0], o.y + a[1], o.z + a[2], o.w + a[3]);
+    }
+  }
+}
+
 // deterministic variant: idx sorted ascending; the block of the FIRST occurrence of a row walks all its duplicates in order and is the
 // only writer of that table row (data parallel: every rank scatters the same gathered list and must end with bit-identical gradients)
 __global__ __launch_bounds__(256) void embedding_bwd_sorted_kernel(const bf16_t* dy, int64_t ldd, const int64_t* idx, int T, int D, int rows, int64_t padding_idx, float* grad, int64_t ldg,
@@ -811,7 +854,12 @@ extern "C" int sam_embedding_bwd(const void* dy, int64_t ldd, const int64_t* idx
                                 void* stream) {
   SAM_REQUIRE(dy && idx && grad, "sam_embedding_bwd: null pointer");
   SAM_REQUIRE(T > 0 && D > 0 && D % 4 == 0 && ldd % 4 == 0 && rows > 0, "sam_embedding_bwd: bad shape");
-  embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg, touched);
+  static int atomic = -1;
+  if (atomic < 0) { const char* e = getenv("SAM_EMBED_BWD_ATOMIC"); atomic = e ? atoi(e) : 0; }       // (A/B: the round-1..4 kernel)
+  if (atomic || ldg % 4 != 0 || ((uintptr_t)grad % 16) != 0)
+    embedding_bwd_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg, touched);
+  else
+    embedding_bwd_dedup_kernel<<<dim3(T), dim3(256), 0, (hipStream_t)stream>>>((const bf16_t*)dy, ldd, idx, T, D, rows, padding_idx, grad, ldg, touched);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

@@ -336,14 +336,12 @@ class GradReducer:
 
 
 def _scatter_rows(grad_table, ids, rows, padding_idx):
-    """grad_table[ids[t], :] += rows[t, :] on the GPU, in a FIXED order: rows are sorted by index (stable) and every table row is summed by
-    one thread block in that order (sam_embedding_bwd_sorted), so all ranks -- which hold the same gathered (index, row) list -- add up
-    bit-identical gradients and the replicas stay in lock-step (atomics would sum in an arbitrary order per rank).
+    """grad_table[ids[t], :] += rows[t, :] on the GPU, in a FIXED order: every table row is summed by ONE thread block -- the block of its first occurrence in
+    the list, which adds the later duplicates in list order (sam_embedding_bwd: no atomics, no sort) -- so all ranks, which hold the same gathered
+    (index, row) list, add up bit-identical gradients and the replicas stay in lock-step (atomics would sum in an arbitrary order per rank).
     There is no CPU implementation in the package: the gloo unit test of GradReducer injects its own `scatter_fn`."""
     from . import ops
-    order = torch.sort(ids, stable=True)
-    rows_sorted = rows.index_select(0, order.indices)
-    ops.embedding_bwd_sorted(rows_sorted if rows_sorted.dtype == torch.bfloat16 else rows_sorted.to(torch.bfloat16), order.values, grad_table, padding_idx)
+    ops.embedding_bwd((rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16)).contiguous(), ids.contiguous(), grad_table, padding_idx)
 
 
 active_reducer = None   # set by the Trainer; EncoderLayerFn.backward reports finished layers to it

@@ -308,7 +308,7 @@ md = mmt_config_dict(3, ("n", "n") + ("s",) * 10, n_dec=30, T=20, n_obj=200, n_o
 torch.manual_seed(0)
 model = M.SAM4C(M.BertConfig.from_dict(md), M.BertConfig.from_dict(text_bert_config_dict()), num_answers=5000, bos_idx=1)
 tr = Trainer(model, base_lr=1e-4, seed=1)
-assert tr.reducer is not None and tr.reducer.check
+assert tr.reducer is not None and tr.reducer.check and tr.reducer.comm is not None
 batch = make_batch(32, *shapes, vocab=5000, device="cuda", seed=2)
 losses = [tr.step(clone_batch(batch)).item() for _ in range(3)]
 torch.cuda.synchronize()
@@ -561,6 +561,8 @@ for dist_on in (True, False):
         model.finetune_modules.insert(0, {"module": model.text_bert, "lr_scale": 0.1})
     tr = Trainer(model, base_lr=1e-3, seed=3)
     assert (tr.reducer is not None) == dist_on
+    if dist_on:
+        assert tr.reducer.comm is not None, "RCCL group: the reducer must enqueue its collectives directly (rccl.py), not through ProcessGroupNCCL Work objects"
     if dist_on and three:
         w = model.text_bert.embeddings.word_embeddings.weight
         red, flat = tr.reducer, tr.flat

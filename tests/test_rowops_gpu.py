@@ -270,6 +270,47 @@ def test_adam_in_gated_pieces_is_bit_identical_to_one_launch():
         ops.adam_step_range(p, gr, m, v, pb, seg, sched, 0, lo + d, sparse=(lo, hi, d, touched.cuda()))
 
 
+def test_embedding_backward_without_atomics_is_deterministic_and_equals_index_add(monkeypatch):
+    """sam_embedding_bwd (TextBert's word table; the data-parallel row-sparse scatter): the block of a row's first occurrence is its only writer and adds the
+    duplicates in list order -- bit-identical run to run, equal to the exact sum in that order, heavy duplication (one row 300 times, spread over several
+    256-position scan chunks), padding / out-of-range / negative ids skipped, touched flags set, an accumulate into a non-zero table; and equal (to fp32
+    rounding) to the atomic kernel it replaces (SAM_EMBED_BWD_ATOMIC=1 is read once per process: checked through index_add here)."""
+    from sam_textvqa_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for T, D, rows in ((1280, 768, 30522), (777, 768, 97), (5, 256, 11), (2600, 1024, 64)):
+        ids = torch.randint(0, rows, (T,), generator=g)
+        ids[: T // 20] = 0                            # padding rows
+        if T > 600:
+            ids[torch.randperm(T, generator=g)[:300]] = 7                 # one row 300 times
+            ids[3], ids[T - 1] = -1, rows + 5                             # (the reducer pads short lists with -1)
+        dy = torch.randn(T, D, generator=g).to(torch.bfloat16)
+        base = torch.randn(rows, D, generator=g)
+        outs = []
+        for _ in range(2):
+            tab = base.clone().cuda()
+            touched = torch.zeros(rows, dtype=torch.uint8).cuda()
+            tab._sam_touched = touched
+            ops.embedding_bwd(dy.cuda(), ids.cuda(), tab, padding_idx=0)
+            outs.append((tab.cpu(), touched.cpu()))
+        assert torch.equal(outs[0][0], outs[1][0])
+        keep = (ids != 0) & (ids >= 0) & (ids < rows)
+        # exact model of the kernel: fp32 sum of the row's dy in list order, then ONE fp32 add into the table
+        ref = base.clone()
+        acc = {}
+        for t in torch.nonzero(keep).flatten().tolist():
+            r = int(ids[t])
+            acc[r] = dy[t].float() if r not in acc else acc[r] + dy[t].float()
+        for r, a in acc.items():
+            ref[r] = base[r] + a
+        assert torch.equal(outs[0][0], ref), (T, D, rows, (outs[0][0] - ref).abs().max().item())
+        exact = base.clone().double()
+        exact.index_add_(0, ids[keep], dy[keep].double())
+        assert (outs[0][0].double() - exact).abs().max().item() < 2e-4 and torch.equal(outs[0][0][0], base[0])
+        flags = torch.zeros(rows, dtype=torch.uint8)
+        flags[ids[keep]] = 1
+        assert torch.equal(outs[0][1], flags)
+
+
 def test_sorted_embedding_backward_is_deterministic_and_equals_index_add():
     """sam_embedding_bwd_sorted (data-parallel row-sparse exchange): one writer per table row, duplicates summed in list order"""
     from sam_textvqa_amd import ops

@@ -160,6 +160,7 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
         assert key in out, key
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
     assert "exposed_comm_ms" in out and out["exposed_comm_ms"] >= 0.0
+    assert out.get("dp_transport") == "rccl-direct"
 
 
 _GRAPH_DP_SCRIPT = r"""
@@ -177,6 +178,8 @@ for mode in ("dp_graph", "dp_eager", "plain_graph", "dp_graph_no_overlap"):
     model, _ = _small_full_model(3, ("n", "s"), (20, 100, 50, 12))
     tr = Trainer(model, base_lr=1e-3, seed=3, use_graph=mode != "dp_eager", overlap=mode != "dp_graph_no_overlap")
     assert (tr.reducer is not None) == (mode != "plain_graph")
+    if mode != "plain_graph":
+        assert tr.reducer.comm is not None            # collectives go straight to RCCL on the reducer's stream (no ProcessGroupNCCL Work objects)
     if mode.startswith("dp_graph"):
         assert tr._dp_capturable() and tr.reducer.overlap == (mode == "dp_graph")
     batch = make_batch(4, vocab=300, device="cuda", seed=21)

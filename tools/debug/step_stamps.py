@@ -63,6 +63,7 @@ def ss(*a, **k):
 ops.sumsq = ss
 _sa = ops.step_advance
 def sa(*a, **k):
+    if sa.n == 0: stamp("step begin")           # (the unpipelined capture opens with step_advance; the pipelined one with _issue_pending_update)
     r = _sa(*a, **k)
     stamp("step_advance %d done" % sa.n)
     sa.n ^= 1
@@ -71,7 +72,7 @@ sa.n = 0
 ops.step_advance = sa
 _ip = trmod.Trainer._issue_pending_update
 def ip(self, bd):
-    stamp("step begin")
+    if "step begin" not in names: stamp("step begin")
     return _ip(self, bd)
 trmod.Trainer._issue_pending_update = ip
 _ap = trmod.Trainer._adam_piece
@@ -82,6 +83,26 @@ def ap(self, lo, hi, gate, max_blocks=0):
     return r
 trmod.Trainer._adam_piece = ap
 
+_ad = ops.adam_step_dev
+def ad(*a, **k):
+    stamp("adam begin")
+    r = _ad(*a, **k)
+    stamp("adam end")
+    return r
+ops.adam_step_dev = ad
+def _wrap_op(nm):
+    f = getattr(ops, nm)
+    state = {"n": 0}
+    def g(*a, **k):
+        i = state["n"] % 2
+        state["n"] += 1
+        stamp("%s #%d begin" % (nm, i))
+        r = f(*a, **k)
+        stamp("%s #%d end" % (nm, i))
+        return r
+    setattr(ops, nm, g)
+_wrap_op("embedding_bwd")
+_wrap_op("embed_sum_bwd")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 model = build_model(3, ("n", "n", "s", "s", "s", "s"), 5000)
 tr = Trainer(model, seed=1, use_graph=True)
