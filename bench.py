@@ -125,6 +125,111 @@ def pmc_traffic(kernel_key):
     return round(sum(v["hbm_bytes"] * v["launches_profiled"] for v in sel) / calls)
 
 
+def live_pmc(args, out_dir=None):
+    """`bench.py --pmc`: re-run this command for 2 steps under `rocprofv3 --kernel-trace --pmc <counters>` -- one pass per counter set, each in its own process,
+    never together with any other trace domain -- and return {short kernel name: {hbm_read_bytes, hbm_write_bytes, hbm_bytes, mfma_util, launches}} per launch,
+    so that `roofline.traffic` / `mfma_util_pmc` come from the box that timed the line.  Corrections as /opt/skills/guides/MI355X_MICROARCH.md prescribes for
+    gfx950 (FETCH_SIZE / WRITE_SIZE in KiB; FETCH_SIZE counts the 128-byte requests of wide coalesced reads as 64: reads = 2 * FETCH_SIZE * 1024), the same
+    arithmetic as tools/summarize_profiles.py (calibrated there on kernels of known byte counts)."""
+    import collections
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return {"error": "rocprofv3 not found"}
+    base = out_dir or os.path.join(ROOT, "gpurun_out", "pmc_live")
+    os.makedirs(base, exist_ok=True)
+    tmp = tempfile.gettempdir()
+    env = dict(os.environ, TMPDIR=tmp)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAM_FORCE_DIST"):
+        env.pop(k, None)
+    child = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", str(args.batch), "--context", str(args.context),
+             "--vocab", str(args.vocab), "--shape", args.shape, "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline", "--no-secondary"]
+    passes = {"FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"], "MFMA": ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]}
+    agg = {}
+    for tag, counters in passes.items():
+        d = os.path.join(base, tag)
+        shutil.rmtree(d, ignore_errors=True)
+        cmd = [exe, "--kernel-trace", "--pmc"] + counters + ["--output-format", "csv", "-d", d, "-o", "bench", "--"] + child
+        try:
+            r = subprocess.run(cmd, env=env, cwd=tmp, capture_output=True, text=True, timeout=900)
+        except Exception as e:
+            return {"error": "%s pass: %s" % (tag, str(e)[:200])}
+        f = None
+        for root_, _, files in os.walk(d):
+            for fn in files:
+                if fn.endswith("counter_collection.csv"):
+                    f = os.path.join(root_, fn)
+        if r.returncode != 0 or f is None:
+            return {"error": "%s pass rc %s: %s" % (tag, r.returncode, (r.stderr or r.stdout)[-300:])}
+        acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+        for row in csv.DictReader(open(f)):
+            name = row["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+            a = acc[name][row["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(row["Counter_Value"])
+        for name, cs in acc.items():
+            e = agg.setdefault(name, {})
+            if tag == "FETCH_SIZE" and "FETCH_SIZE" in cs:
+                e["launches"] = cs["FETCH_SIZE"][0]
+                e["hbm_read_bytes"] = round(2.0 * 1024 * cs["FETCH_SIZE"][1] / cs["FETCH_SIZE"][0])
+            if tag == "WRITE_SIZE" and "WRITE_SIZE" in cs:
+                e["hbm_write_bytes"] = round(1024.0 * cs["WRITE_SIZE"][1] / cs["WRITE_SIZE"][0])
+            if tag == "MFMA" and cs.get("GRBM_GUI_ACTIVE", [0, 0])[1] > 0:
+                busy = cs["SQ_VALU_MFMA_BUSY_CYCLES"][1] / max(cs["SQ_VALU_MFMA_BUSY_CYCLES"][0], 1)
+                gui = cs["GRBM_GUI_ACTIVE"][1] / cs["GRBM_GUI_ACTIVE"][0]           # summed over the 8 XCDs
+                e["mfma_util"] = round(busy / (gui / 8 * 1024), 4)
+    for e in agg.values():
+        if "hbm_read_bytes" in e and "hbm_write_bytes" in e:
+            e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
+    return agg
+
+
+_LIVE_NAMES = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel", "attn_bwd_fused_long_kernel"], "gemm_grouped_wgrad": ["gemm8w_kernel", "gemm_group_kernel"]}
+
+
+def apply_live_pmc(res, live):
+    """merge the counters of `live_pmc` into the line's roofline objects (dominant kernel + the attention rows), replacing the committed-file figures"""
+    if "error" in live:
+        res["pmc_live"] = live
+        return
+    src = "live: rocprofv3 --kernel-trace --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE, one process each, 2 steps) run by this bench.py --pmc invocation on this box; gfx950 corrections applied"
+
+    def pick(key):
+        base, _, n_tok = key.partition("@N=")
+        names = _LIVE_NAMES.get(base)
+        if not names:
+            return None
+        sel = [(k, v) for k, v in live.items() if any(k.startswith(n) for n in names) and "hbm_bytes" in v]
+        if n_tok:
+            import re
+            nkt = next(t for t in (2, 4, 8, 12, 16, 24) if t * 16 >= int(n_tok))
+            sel = [(k, v) for k, v in sel if re.search(r"<%d[,>]" % nkt, k) or "long_kernel" in k]
+        if not sel:
+            return None
+        n = sum(v.get("launches", 1) for _, v in sel)
+        out = {"hbm_bytes": round(sum(v["hbm_bytes"] * v.get("launches", 1) for _, v in sel) / n)}
+        mu = [v["mfma_util"] for _, v in sel if "mfma_util" in v]
+        if mu:
+            out["mfma_util"] = round(sum(mu) / len(mu), 4)
+        return out
+    roof = res.get("roofline")
+    if roof:
+        got = pick(roof["kernel"])
+        if got:
+            roof["traffic"], roof["traffic_source"] = got["hbm_bytes"], src
+            if "mfma_util" in got:
+                roof["mfma_util_pmc"], roof["mfma_util_pmc_source"] = got["mfma_util"], src
+    for key, v in (res.get("roofline_attention") or {}).items():
+        if isinstance(v, dict):
+            got = pick(key)
+            if got:
+                v["traffic"], v["traffic_source"] = got["hbm_bytes"], src
+    res["pmc_live"] = {k: v for k, v in sorted(live.items(), key=lambda kv: -kv[1].get("hbm_bytes", 0))[:14]}
+
+
 def pmc_mfma_util(kernel_key):
     """MFMA-pipe utilisation of `kernel_key` from the committed PMC summary (profiles/*_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES over
     the kernel's SIMD-cycles, a separate rocprofv3 --pmc pass of this same command); None when no summary is committed"""
@@ -378,7 +483,7 @@ def dist_one_rank(args):
         if r.returncode != 0 or not line:
             return {"error": (r.stderr or r.stdout)[-300:]}
         d = json.loads(line[-1])
-        out = {k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "slow_steps", "exposed_comm_ms", "overlap", "grad_payload", "step_mode", "rccl_ranks_seen")}
+        out = {k: d.get(k) for k in ("value", "ms_per_step", "ms_per_step_median", "slow_steps", "exposed_comm_ms", "overlap", "grad_payload", "step_mode", "rccl_ranks_seen", "dp_transport")}
         # the same captured step with the collectives AFTER the backward instead of underneath it: replayed graph against replayed graph
         r2 = subprocess.run(cmd + ["--no-overlap"], env=dict(env, MASTER_PORT=str(port + 1)), capture_output=True, text=True, timeout=600, cwd=ROOT)
         line2 = [l for l in r2.stdout.splitlines() if l.startswith("{")]
@@ -406,6 +511,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--rotate", type=int, default=16, help="distinct synthetic batches whose token ids / masks / targets take turns (1 = replay one batch, as rounds 1-3 did)")
+    ap.add_argument("--pmc", action="store_true", help="after the timed region: re-run 2 steps of this command under rocprofv3 --pmc (three separate passes) and put the HBM bytes / MFMA "
+                                                       "utilisation of the dominant kernel and the attention kernels into the line (roofline.traffic from THIS box); off by default (~3 min)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows (c=5, stress, north-star literal shape, decoding, 1-rank data-parallel step)")
     args = ap.parse_args()
 
@@ -534,6 +641,8 @@ def main():
         res["gemm_by_shape"] = extra.pop("gemm_by_shape", [])
         res["roofline_attention"] = extra
         res["kernels"] = table
+    if world == 1 and args.pmc and "roofline" in res:
+        apply_live_pmc(res, live_pmc(args))
     if ranks_seen is not None:
         res["rccl_ranks_seen"] = ranks_seen          # all-reduce of a one per rank over the reducer's group, just before the timed region
         res["dist_backend"] = parallel.dist.get_backend()
