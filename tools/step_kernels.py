@@ -32,3 +32,9 @@ for i, r in enumerate(step):
         run += 1; continue
     if run: print("      ... %d hot" % run); run = 0
     print("%4d %6.1f  %s" % (i, dur(r), short(r["Kernel_Name"])))
+if "--census" in sys.argv:
+    # every node of ONE replayed step in launch order: index, start (us after the step's first kernel), duration, queue, kernel
+    t0 = int(step[0]["Start_Timestamp"])
+    print("---- census of one replayed step: %d kernels (of which %d copyBuffer / fillBuffer)" % (len(step), sum(1 for r in step if "rocclr" in r["Kernel_Name"])))
+    for i, r in enumerate(step):
+        print("%4d %9.1f %8.1f  q%-3s %s" % (i, (int(r["Start_Timestamp"]) - t0) / 1e3, dur(r), r.get("Queue_Id", "?"), short(r["Kernel_Name"])))
