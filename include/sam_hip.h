@@ -95,7 +95,8 @@ int sam_attn_dec_row(const void* qkv_enc, const void* qkv_dec, const uint32_t* a
 int sam_attn_fwd_train(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, int B, int N, int H,
                        int head_dim, float scale, float p_drop, uint64_t seed, uint64_t offset, void* out, void* out_lo, float* lse2,
                        uint32_t* keep, void* stream);
-/* autograd of sam/sa_m4c.py:563-598 in ONE pass (N <= sam_attn_bwd_fused_max_n() = 192 keys; SAM_ERR_UNSUPPORTED beyond, use sam_attn_bwd): one workgroup
+/* autograd of sam/sa_m4c.py:563-598 in ONE pass (N <= sam_attn_bwd_fused_max_n() = 384 keys: up to 192 one sub-problem per (batch, head), 193..384 as 2 x 2
+ * sub-problems of 192 -- the "long" kernel; SAM_ERR_UNSUPPORTED beyond, sam_attn_bwd is the two-kernel form): one workgroup
  * per (batch, head) stages Q, K, dO once (block-scaled fp16), computes S, P, dP and dS once per score and uses them for dK, dV (in registers) and dQ
  * (through an LDS exchange of dS).  out / out_lo: the forward's output and residual (sam_attn_fwd_train); keep: its dropout bits (NULL when p_drop = 0). */
 int sam_attn_bwd_fused(const void* dout, const void* qkv, const void* out, const void* out_lo, const float* lse2, const uint32_t* allow,

@@ -463,6 +463,7 @@ class DeferredWgrads:
     late_stream, late = None, []
     side_stream = None
     held = []                   # [(jobs, layers, acc, event)]: the MMT's last group, waiting for TextBert's problems (flush)
+    extra_events = []           # one event per extra, recorded where its operands were produced
     extras = []                 # weight gradients of nn.Linear sites outside the encoder layers (classifier, pointer-net q / k), waiting for the next MMT group
     late_armed = False          # set by whoever will call join() before it reads the gradients (Trainer._eager_step); plain autograd use never leaves the issuing stream
 
@@ -493,6 +494,9 @@ class DeferredWgrads:
             return False
         if dy.data_ptr() % 16 or x.data_ptr() % 16 or dw.data_ptr() % 16:
             return False
+        ev = torch.cuda.Event()
+        ev.record()                         # the operands were produced on THIS stream (the pointer net's run on the model's side stream): the launch that takes
+        cls.extra_events.append(ev)         # them -- on whatever stream it goes out -- waits for the event, not for the autograd engine's implicit ordering
         cls.extras.append(job)
         return True
 
@@ -563,6 +567,10 @@ class DeferredWgrads:
             cls.late.append(jobs)                 # operands were allocated on the issuing stream: alive until join()
             return
         if cls.extras and len(jobs) + len(cls.extras) <= 20:
+            cls._wait_extras()
+            cls.late.append(cls.extras)     # (allocated on another stream: alive until join())
+            if cls.late_stream is None:
+                cls.late_stream = torch.cuda.current_stream()
             jobs, cls.extras = list(jobs) + cls.extras, []
         if jobs:
             ops.wgrad_grouped(jobs, accumulate=bool(acc))
@@ -573,8 +581,19 @@ class DeferredWgrads:
     def flush_extras(cls):
         """extras that found no MMT group to ride on (a model whose only group is the late one): launched by themselves, here"""
         if cls.extras:
+            cls._wait_extras()
             jobs, cls.extras = cls.extras, []
             ops.wgrad_grouped(jobs, accumulate=True)
+            cls.late.append(jobs)
+            if cls.late_stream is None:
+                cls.late_stream = torch.cuda.current_stream()
+
+    @classmethod
+    def _wait_extras(cls):
+        cur = torch.cuda.current_stream()
+        for ev in cls.extra_events:
+            cur.wait_event(ev)
+        cls.extra_events = []
 
     @classmethod
     def join(cls):
@@ -586,7 +605,7 @@ class DeferredWgrads:
     @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
-        cls.held, cls.extras = [], []
+        cls.held, cls.extras, cls.extra_events = [], [], []
         if cls.late:                 # a launch may still be reading its operands on the late stream: the issuing stream waits before they are dropped
             try:
                 torch.cuda.current_stream().wait_stream(cls.late_stream)
@@ -635,7 +654,7 @@ class EncoderLayerFn(Function):
             return outs[0]
         ctx.coarse = False
         qkv = ops.gemm(x, wqkv, epilogue=capi.EPI_BIAS, bias=bqkv)
-        fused_bwd = x.shape[0] // batch <= ops.attn_bwd_fused_max_n()
+        fused_bwd = x.shape[0] // batch <= ops.attn_bwd_fused_max_n() and os.environ.get("SAM_ATTN_BWD_FUSED", "1") != "0"     # (the residual is only written for a backward that reads it)
         if fused_bwd:       # the one-pass attention backward takes delta from the output and its rounding residual
             ctxv, lse2, keep, ctx_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_attn, *seeds[0], want_residual=True)
         else:
@@ -745,7 +764,7 @@ class AttentionFn(Function):
     def forward(ctx, qkv, allow, batch, heads, scale, p_drop):
         qkv = qkv.contiguous()
         seed = dropout_clock.next()
-        if qkv.shape[0] // batch <= ops.attn_bwd_fused_max_n():
+        if qkv.shape[0] // batch <= ops.attn_bwd_fused_max_n() and os.environ.get("SAM_ATTN_BWD_FUSED", "1") != "0":
             out, lse2, keep, out_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed, want_residual=True)
         else:
             (out, lse2, keep), out_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed), None

@@ -162,12 +162,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> attn_fwd_train(const Tensor& qkv, con
 }
 
 static bool fused_attn_bwd_enabled(int64_t n) {
-  static int e = -1;
-  if (e < 0) {
-    const char* s = getenv("SAM_ATTN_BWD_FUSED");
-    e = (s && s[0] == '0') ? 0 : 1;
-  }
-  return e && n <= sam_attn_bwd_fused_max_n();
+  // read on every call, as ops.attn_bwd does: a test or an A/B script that flips SAM_ATTN_BWD_FUSED between calls must see the same route on the
+  // per-kernel (Python) path and on this coarse one
+  const char* s = getenv("SAM_ATTN_BWD_FUSED");
+  return !(s && s[0] == '0') && n <= sam_attn_bwd_fused_max_n();
 }
 
 Tensor attn_bwd_fused(const Tensor& dout, const Tensor& qkv, const Tensor& out, const Tensor& out_lo, const Tensor& lse2, const Tensor& allow, const Tensor& keep,

@@ -226,8 +226,8 @@ def attn_bwd_fused_max_n():
 
 
 def attn_bwd(dout, qkv, lse2, allow, keep, batch, n_heads, scale, p_drop=0.0, out=None, out_lo=None):
-    """-> dqkv bf16 [B*N, 3*H*64].  With the forward's output and residual (attn_fwd(..., want_residual=True)) and N <= 192 this is the one-pass
-    kernel (sam_attn_bwd_fused); otherwise the two-kernel form (sam_attn_bwd: a dQ pass that also produces delta, then dK / dV)."""
+    """-> dqkv bf16 [B*N, 3*H*64].  With the forward's output and residual (attn_fwd(..., want_residual=True)) and N <= attn_bwd_fused_max_n() (384: 193..384 keys run
+    as 2 x 2 sub-problems of 192) this is the one-pass kernel (sam_attn_bwd_fused); otherwise the two-kernel form (sam_attn_bwd: a dQ pass that also produces delta, then dK / dV)."""
     _chk(dout, BF16, "dout"); _chk(qkv, BF16, "qkv")
     rows, three_d = qkv.shape
     n = rows // batch
