@@ -457,7 +457,18 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
   const int kt = (a.K + BK - 1) / BK;
   const int64_t per_split = ((int64_t)a.M * a.N + a.M) * (int64_t)sizeof(float);
   const int tn = (a.N + 127) / 128;
-  if (want_split == 0 && (force_tile == 0 || force_tile >= 1000)) {
+  if (want_split == 0 && (force_tile == 0 || force_tile >= 12000)) {
+    // the 12-wave kernels with loader waves (gemm12.hip) are the first choice for the large products (SAM_GEMM12=0: the 8-wave kernels, for an A/B);
+    // force_tile 12192 / 12448 forces one
+    static int v12 = -1;
+    if (v12 < 0) { const char* e = getenv("SAM_GEMM12"); v12 = e ? atoi(e) : 1; }
+    if (v12 || force_tile >= 12000) {
+      const int rc = gemm12_launch(a, (AKC ? 2 : 0) | (BKC ? 1 : 0), EPI, sizeof(OutT) == 4, force_tile, st);
+      if (rc != SAM_ERR_UNSUPPORTED) { if (a.split_used) *a.split_used = 1; return rc; }
+      if (force_tile >= 12000) { sam_set_error("sam_gemm_bf16: force_tile=%d: the 12-wave kernels have no instance for this problem", force_tile); return rc; }
+    }
+  }
+  if (want_split == 0 && (force_tile == 0 || (force_tile >= 1000 && force_tile < 12000))) {
     // large problems: the 8-wave persistent kernels (gemm8.hip); they decline (SAM_ERR_UNSUPPORTED) what they have no instance for
     static int v2 = -1;
     if (v2 < 0) { const char* e = getenv("SAM_GEMM8"); v2 = e ? atoi(e) : 1; }
@@ -697,7 +708,7 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;
-  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192 || ft == 1128, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1128, 1192, 1256, 1448 or 3192");
+  SAM_REQUIRE(ft == 0 || ft == 64 || ft == 128 || ft == 160 || ft == 192 || ft == 256 || ft == 1192 || ft == 1256 || ft == 1448 || ft == 3192 || ft == 1128 || ft == 12192 || ft == 12448, "sam_gemm_bf16: force_tile must be 0, 64, 128, 160, 192, 256, 1128, 1192, 1256, 1448, 3192, 12192 or 12448");
   const int lay = (d->a_kcontig ? 2 : 0) | (d->b_kcontig ? 1 : 0);
   const int e = d->epilogue;
   if (lay == 3) {  // forward: x[M,K] . W[N,K]^T

@@ -311,6 +311,8 @@ inline int device_cu_count() {
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.
 int gemm8_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
+// 12-wave kernels with loader waves (gemm12.hip): 192 x 192 (three stages) / 192 x 256 tiles; tile: 0 = heuristic, 12192 / 12448 = force one.  Same contract.
+int gemm12_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int tile, hipStream_t st);
 // (the round-3 experiment with two 4-wave blocks per CU, 256 x 128 x 32 tiles, measured 0.78x the 8-wave k-loop: it lives in tools/probes/gemm4.hip, outside the library)
 // grouped weight gradients on the 8-wave core (gemm8w.hip): 256x256 tiles, the K range of each tile split over a PAIR of blocks that exchange
 // halves inside the launch.  descs[0].ws / ws_bytes: the exchange workspace (gemm8w_ws_bytes(total tiles); its first words are the pair flags,

@@ -192,7 +192,7 @@ def test_both_tile_configs_all_layouts(tile):
     assert_close_bf16(db, dyy.float().sum(0), ulps=0, name="bias grad")
 
 
-@pytest.mark.parametrize("tile", [1192, 3192, 1256, 1448, 1128])      # 3192: 192x192 with the deferred (sliced, LDS-staged) epilogue (opt-in: measured slower); 1448: 192x256
+@pytest.mark.parametrize("tile", [1192, 3192, 1256, 1448, 1128, 12192, 12448])      # 12192 / 12448: the 12-wave kernels with loader waves (gemm12.hip); 3192: 192x192 with the deferred (sliced, LDS-staged) epilogue (opt-in: measured slower); 1448: 192x256
 @pytest.mark.parametrize("M,N,K", [(3500, 3080, 128), (600, 520, 64), (4000, 2304, 192), (256, 256, 704), (11648, 768, 768)])
 def test_eight_wave_persistent_kernels(tile, M, N, K):
     """gemm8.hip (256x256 / 192x192 tiles, one block per CU walking several tiles): ragged M and N, one to eleven k-tiles per tile, more tiles
@@ -227,6 +227,16 @@ def test_eight_wave_persistent_kernels(tile, M, N, K):
     assert_close_bf16(ops.gemm(big[:, 64:], wg, force_tile=tile), big[:, 64:].float().cpu() @ w.float().t(), name="lda view")
     # bit-reproducible
     assert torch.equal(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile))
+    if tile >= 12000:
+        # the loader-wave kernels compute every tile exactly as the 8-wave kernels of the same tile shape do (same fragments, same MFMA order, same epilogue):
+        # bit-identical outputs, several times over (a race between the loader waves' DMA and the compute waves' reads would show as a rare wrong tile)
+        same = {12192: 1192, 12448: 1448}[tile]
+        for _ in range(4):
+            assert torch.equal(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=tile), ops.gemm(xg, wg, epilogue=capi.EPI_BIAS, bias=bg, force_tile=same))
+            assert torch.equal(ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=prev.cuda(), force_tile=tile),
+                               ops.gemm(xg, wT.cuda(), b_kcontig=False, epilogue=capi.EPI_MUL_AUX, aux_in=prev.cuda(), force_tile=same))
+            assert torch.equal(ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), p_drop=0.1, seed=11, offset=3, force_tile=tile),
+                               ops.gemm(xg, wg, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bg, residual=res.cuda(), p_drop=0.1, seed=11, offset=3, force_tile=same))
 
 
 def test_short_k_problem_that_fills_the_chip_once_takes_the_two_block_configuration():
