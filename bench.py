@@ -107,12 +107,12 @@ def pmc_traffic(kernel_key):
     if m:
         tf = {"0": "false", "1": "true"}
         pat = re.compile(r"gemm_kernel<\d+, \d+, \d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
-        pat8 = re.compile(r"gemm8_kernel<\d+, \d+, %s, %s, %s, %s>" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
+        pat8 = re.compile(r"gemm(8|12)_kernel<\d+, \d+, %s, %s, %s, %s[,>]" % (tf[m.group(1)], tf[m.group(2)], m.group(3), "float" if m.group(4) == "1" else "unsigned short"))
         sel = [v for k, v in kern.items() if pat.match(k) or pat8.match(k)]
     else:
         base, _, n_tok = kernel_key.partition("@N=")
         names = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(dq+dkdv)": ["attn_bwd_dq_kernel", "attn_bwd_dkdv_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel", "attn_bwd_fused_long_kernel"],
-                 "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel"]}.get(base, [base.replace("sam_", "")])
+                 "gemm_grouped_wgrad": ["gemm_group_kernel", "gemm8w_kernel", "gemm12w_kernel"]}.get(base, [base.replace("sam_", "")])
         sel = [(k, v) for k, v in kern.items() if any(k.startswith(n) for n in names)]
         if n_tok:      # attention kernels are templated on the number of 16-key tiles: keep the instantiation this sequence length runs
             nkt = next(t for t in (2, 4, 8, 12, 16, 24) if t * 16 >= int(n_tok))
@@ -187,7 +187,7 @@ def live_pmc(args, out_dir=None):
     return agg
 
 
-_LIVE_NAMES = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel", "attn_bwd_fused_long_kernel"], "gemm_grouped_wgrad": ["gemm8w_kernel", "gemm_group_kernel"]}
+_LIVE_NAMES = {"attn_fwd": ["attn_fwd_kernel"], "attn_bwd(fused)": ["attn_bwd_fused_kernel", "attn_bwd_fused_long_kernel"], "gemm_grouped_wgrad": ["gemm12w_kernel", "gemm8w_kernel", "gemm_group_kernel"]}
 
 
 def apply_live_pmc(res, live):
@@ -241,7 +241,8 @@ def pmc_mfma_util(kernel_key):
     _PMC_MFMA_FILE = os.path.relpath(files[-1], ROOT)
     kern = json.load(open(files[-1]))["kernels"]
     if kernel_key == "gemm_grouped_wgrad":
-        sel = [v for k, v in kern.items() if k.startswith("gemm8w_kernel")] or [v for k, v in kern.items() if k.startswith("gemm_group_kernel")]
+        sel = [v for k, v in kern.items() if k.startswith("gemm12w_kernel")] or [v for k, v in kern.items() if k.startswith("gemm8w_kernel")] or \
+              [v for k, v in kern.items() if k.startswith("gemm_group_kernel")]
         return sel[0]["mfma_util"] if sel else None
     return None
 

@@ -558,7 +558,17 @@ static int grouped_impl(const sam_gemm_desc* descs, int count, void* stream, con
   {
     static int use8 = -1;
     if (use8 < 0) { const char* e = getenv("SAM_GEMM8W"); use8 = e ? atoi(e) : 1; }
-    SAM_REQUIRE(ft == 0 || ft == 128 || ft == 1256, "sam_gemm_bf16_grouped: force_tile must be 0, 128 or 1256");
+    SAM_REQUIRE(ft == 0 || ft == 128 || ft == 1256 || ft == 12448, "sam_gemm_bf16_grouped: force_tile must be 0, 128, 1256 or 12448");
+    // the loader-wave grouped kernel (gemm12w.hip): opt-in (SAM_GEMM12W=1; force_tile 12448 forces it).  Measured SLOWER than the 8-wave kernel below on the
+    // step's sets -- the weight-gradient loop is bound by L2 -> LDS bytes (~8 TB/s chip-wide for k-strided 128-byte segments), and a 192 x 256 tile moves 17 % more
+    // bytes per flop than a 256 x 256 one: pair alone 440 vs 367 us although its 256 CUs are all busy (profiles/r5_gemm_experiments.txt).
+    static int use12 = -1;
+    if (use12 < 0) { const char* e = getenv("SAM_GEMM12W"); use12 = e ? atoi(e) : 0; }
+    if ((use12 && ft == 0) || ft == 12448) {
+      const int rc = gemm12w_grouped(descs, count, (hipStream_t)stream);
+      if (rc == SAM_OK) return SAM_OK;
+      SAM_REQUIRE(rc == SAM_ERR_UNSUPPORTED && ft != 12448, "sam_gemm_bf16_grouped: the loader-wave grouped kernel cannot run this problem set (fewer deep tiles than CUs, K %% 64, workspace)");
+    }
     if ((use8 && ft == 0) || ft == 1256) {
       const int rc = gemm8w_grouped(descs, count, (hipStream_t)stream);
       if (rc == SAM_OK) return SAM_OK;
@@ -594,7 +604,8 @@ extern "C" int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int cou
   if (!descs || count < 1 || count > SAM_MAX_GROUP8) return 0;
   int tiles = 0;
   for (int q = 0; q < count; ++q) tiles += ((descs[q].M + 255) / 256) * ((descs[q].N + 255) / 256);
-  return gemm8w_ws_bytes(tiles);
+  const int64_t a = gemm8w_ws_bytes(tiles), b = gemm12w_ws_bytes(descs, count);
+  return a > b ? a : b;
 }
 
 extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream) {

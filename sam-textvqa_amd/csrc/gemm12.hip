@@ -245,6 +245,11 @@ int pick12(const GemmArgs& a, int tile, hipStream_t st) {
 int samgemm::gemm12_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, int tile, hipStream_t st) {
   GemmArgs a = a_in;
   { static int dbg = -1; if (dbg < 0) { const char* v = getenv("SAM_GEMM8_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg & 1; }
+  if (lay == 0 && c_is_f32 && e == SAM_EPI_NONE && tile == 12448 && a.K % BK == 0 && a.bias_grad == nullptr && a.M % 8 == 0) {
+    // (experiment: the weight-gradient layout -- both operands k-strided, fp32 accumulate -- on the loader-wave core, one problem; profiles/r5_gemm_experiments.txt)
+    if ((int64_t)a.K * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)a.K * a.ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;
+    return launch12<192, 256, false, false, SAM_EPI_NONE, float, 2>(a, device_cu_count(), st);
+  }
   if (a.K % BK != 0 || a.split_k > 1 || a.bias_grad != nullptr || c_is_f32 || !(lay & 2)) return SAM_ERR_UNSUPPORTED;
   const int64_t a_rows = a.M, b_rows = (lay & 1) ? a.N : a.K;
   if (a_rows * a.lda * 2 >= (int64_t)0x7fffffff || b_rows * a.ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;

@@ -318,6 +318,10 @@ int gemm12_launch(const GemmArgs& a, int lay, int epilogue, int c_is_f32, int ti
 // halves inside the launch.  descs[0].ws / ws_bytes: the exchange workspace (gemm8w_ws_bytes(total tiles); its first words are the pair flags,
 // which must be zero before the first launch and are left zero by every launch).  SAM_ERR_UNSUPPORTED: not a problem set for this kernel.
 int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st);
+// grouped weight gradients on the loader-wave core (gemm12w.hip): 192 x 256 tiles, one persistent workgroup per CU on a static schedule (whole tiles, then one
+// K slice of a left-over tile with an in-launch fixed-order reduction, then the shallow tiles).  Same contract; workspace gemm12w_ws_bytes (0 = none needed / not a set for it).
+int gemm12w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st);
+int64_t gemm12w_ws_bytes(const sam_gemm_desc* descs, int count);
 int64_t gemm8w_ws_bytes(int tiles);
 
 }  // namespace samgemm

@@ -411,6 +411,55 @@ def test_grouped_wgrad_more_than_twelve_problems_the_eight_wave_kernel_declines(
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
 
 
+@pytest.mark.parametrize("R", [1472, 2048])
+def test_grouped_wgrad_loader_wave_kernel_pair_slices_and_shallow_tiles(R):
+    """gemm12w.hip: an MMT layer pair is 288 tiles of 192 x 256 -- 256 whole tiles (one per CU), then the K range of the 32 left-over tiles in 8 slices each, summed inside
+    the launch in a fixed order; TextBert-size and head-size problems follow as whole shallow tiles.  Against fp32, fused bias gradients (whole tiles AND sliced
+    tiles carry them), accumulate and overwrite, bit-identical run to run and equal (to fp32 summation order) to the 8-wave kernel; the exchange's counters are
+    back at zero and its error word clear after every launch.  R = 1472: 23 k-tiles per tile, seven slices of 3 and one of 2."""
+    ops, capi = _mods()
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    deep, deep_ref = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6))          # (3072 x 768 with bias: its first tile column includes sliced tiles)
+    ops.wgrad_grouped(deep, force_tile=12448)
+    ops.grouped_ws_check()
+    for (dy, x, dw, db), (rw, rb) in zip(deep, deep_ref):
+        assert_close_bf16(dw, rw, ulps=0, name="loader-wave grouped wgrad")
+        if db is not None:
+            assert_close_bf16(db, rb, ulps=0, name="loader-wave grouped bias grad")
+    first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in deep]
+    for _ in range(3):                                    # fresh accumulators, same inputs: bit-identical, launch after launch (also: counters really returned to zero)
+        again, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6))
+        ops.wgrad_grouped(again, force_tile=12448)
+        for (a, b), j in zip(first, again):
+            assert torch.equal(a, j[2]) and (b is None or torch.equal(b, j[3]))
+    ops.grouped_ws_check()
+    old, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6))
+    ops.wgrad_grouped(old, force_tile=1256)               # the 8-wave kernel: same products, fp32 sums in another order
+    for (a, b), j in zip(first, old):
+        assert float((a - j[2]).abs().max()) <= 2e-4 * (1.0 + float(j[2].abs().max()))
+        assert b is None or float((b - j[3]).abs().max()) <= 2e-4 * (1.0 + float(j[3].abs().max()))
+    # with shallow problems behind the pair (TextBert's three layers at 320 rows, a ragged head-size problem), any order; overwrite == accumulate into zero
+    shal, shal_ref = _wgrad_jobs(320, shapes * 2 + [(5000, 768), (768, 768)], seed0=600, bias=(1, 2, 8))
+    d2, d2_ref = _wgrad_jobs(R, shapes * 2, seed0=700, bias=(2, 7))
+    mixed = shal[:3] + d2 + shal[3:]
+    ops.wgrad_grouped(mixed, force_tile=12448)
+    for (dy, x, dw, db), (rw, rb) in zip(d2 + shal, d2_ref + shal_ref):
+        assert_close_bf16(dw, rw, ulps=0, name="loader-wave mixed-depth wgrad")
+        if db is not None:
+            assert_close_bf16(db, rb, ulps=0, name="loader-wave mixed-depth bias grad")
+    junk = [(dy, x, torch.full_like(dw, 3.5), None if db is None else torch.full_like(db, -1.0)) for dy, x, dw, db in mixed]
+    ops.wgrad_grouped(junk, force_tile=12448, accumulate=False)
+    zero = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in mixed]
+    ops.wgrad_grouped(zero, force_tile=12448)
+    for a, b in zip(zero, junk):
+        assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
+    ops.grouped_ws_check()
+    # a set with fewer deep tiles than CUs is not one for this kernel: forcing it is an error, the default goes to the 8-wave kernel
+    one, _ = _wgrad_jobs(R, shapes)
+    with pytest.raises(capi.SamHipError):
+        ops.wgrad_grouped(one, force_tile=12448)
+
+
 def test_grouped_wgrad_eight_wave_ragged_and_unsplit():
     """tile edges (M, N multiples of 8 but not of 256), a single problem, and a problem set with too many tiles for pairs (one block per tile)"""
     ops, capi = _mods()

@@ -14,7 +14,7 @@ def short(n):
     return n[:100]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 tot = sum(dur(r) for r in step)
-ours = ("gemm_", "attn_", "ln_", "partial_finalize", "splitk", "adam", "sumsq", "bce_", "ptr_", "spatial_", "prefix_lm", "relation_", "embedding_bwd_kernel",
+ours = ("gemm_", "gemm8", "gemm12", "copy_blocks", "enc_", "step_advance", "pack_masks", "ge_u8", "add_dropout", "embedding_bwd", "attn_", "ln_", "partial_finalize", "splitk", "adam", "sumsq", "bce_", "ptr_", "spatial_", "prefix_lm", "relation_", "embedding_bwd_kernel",
         "l2norm_pack", "embed_", "gather2", "cast_bf16", "colsum", "from_additive", "from_int8")
 torch_us = sum(dur(r) for r in step if not any(h in r["Kernel_Name"] for h in ours))
 print("%d kernels, %.1f us busy, span %.1f us; torch-native: %d kernels, %.1f us (%.1f%%)" % (
