@@ -42,12 +42,13 @@ def mixed():
     R = 64 * 182
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
     g = torch.Generator(device="cuda").manual_seed(0)
+    pad = int(os.environ.get("PAD", "0"))          # experiment: leading dimensions padded by PAD elements (L2 channel conflicts of power-of-two-ish row strides?)
     def mk(rows, n):
         out = []
         for _ in range(n):
             for m, k in shapes:
-                dy = (torch.randn(rows, m, device="cuda", generator=g) * 0.5).bfloat16()
-                x = (torch.randn(rows, k, device="cuda", generator=g) * 0.5).bfloat16()
+                dy = (torch.randn(rows, m + pad, device="cuda", generator=g) * 0.5).bfloat16()[:, :m]
+                x = (torch.randn(rows, k + pad, device="cuda", generator=g) * 0.5).bfloat16()[:, :k]
                 out.append((dy, x, torch.zeros(m, k, device="cuda"), torch.zeros(m, device="cuda")))
         return out
     pair, tb = mk(R, 2), mk(1280, 3)
