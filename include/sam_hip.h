@@ -153,8 +153,10 @@ typedef struct sam_gemm_desc {
   float* bias_grad;   /* wgrad layout (0,0) only: bias_grad[m] (+)= sum_k A(m,k), i.e. the bias gradient colsum(dy), fused into the wgrad;
                          added to the old value when `accumulate`, overwritten otherwise (like C). */
   float* ws; int64_t ws_bytes;   /* split-K scratch: split_k * (M*N + M) floats */
-  int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height of the 4-wave kernels; 1192 / 1256 / 1448: force the 8-wave
-                         persistent kernel with 192x192 / 256x256 / 192x256 tiles (testing, tuning) */
+  int32_t force_tile; /* 0: heuristic; 64 / 128 / 160 / 192 / 256: force that block-tile height of the 4-wave kernels; 1192 / 1256 / 1448 (1128): force the 8-wave
+                         persistent kernel with 192x192 / 256x256 / 192x256 (128x128, two blocks per CU) tiles; 12192 / 12448: force the 12-wave kernel with loader
+                         waves (192x192 three-stage / 192x256) -- testing, tuning.  Grouped call: 0, 128 (4-wave), 1256 (8-wave pair exchange) or 12448 (loader-wave
+                         kernel with the whole-tile + K-slice schedule) in descs[0] */
   int32_t defer_reduce;  /* split-K only: 1 = leave the partials in ws and let the caller run sam_gemm_splitk_reduce (separately timeable) */
   int32_t split_k_used;  /* OUT: the split factor that was launched (1 = no split, nothing to reduce) */
   sam_ln_fuse* ln;       /* optional (NULL = none): see sam_ln_fuse */
@@ -169,7 +171,8 @@ int sam_gemm_bf16_grouped(const sam_gemm_desc* descs, int count, void* stream);
 /* Workspace of the grouped call.  With descs[0].ws / ws_bytes >= this many bytes (16-byte aligned, ZERO-FILLED once by the caller, private to one
  * stream; every launch leaves its flag words zero again) and every K a multiple of 64, the call runs 256x256 tiles on the 8-wave kernel with each
  * tile's K range split over a PAIR of workgroups that exchange accumulator halves inside the launch (fixed summation order, no atomics).
- * Without it the 128x128 4-wave kernel runs.  descs[0].force_tile: 0 = choose, 128 = 4-wave kernel, 1256 = 8-wave kernel or error.
+ * Without it the 128x128 4-wave kernel runs.  descs[0].force_tile: 0 = choose, 128 = 4-wave kernel, 1256 = 8-wave kernel or error, 12448 = the loader-wave
+ * kernel (gemm12w.hip; opt-in, also by SAM_GEMM12W=1: measured slower on the step's sets) or error; the size returned below covers whichever kernel runs.
  * The first 32-bit word of the workspace is an ERROR word: the pair wait is bounded (~1 s), a block whose partner never became resident raises it
  * and finishes with an undefined result instead of hanging the device; a caller that reads a non-zero word there must discard that step. */
 int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int count);
