@@ -38,12 +38,18 @@ __device__ __forceinline__ void dma_range(const bf16_t* base, unsigned char* dst
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(dst + s * 1024), 16, off[s], soff, 0, 0);
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST>
+// PH = read / MFMA phases per k-tile.  2: gemm8's schedule (phase 0: all B fragments + the upper A rows, phase 1: the lower A rows).  1 (192 x 192, three stages
+// only): ALL fragments of a k-tile in one read segment, all 36 MFMAs in one MFMA segment -- two barriers per k-tile instead of four.  With 18 MFMAs per phase
+// (306 cycles) the fixed costs of a phase (barrier, fragment-read latency, lgkmcnt drain) were as long as the work they separate: 538 cycles per interval
+// measured.  It needs both halves of the A fragments at once (48 + 24 fragment registers next to 72 accumulators: fits 168) and a third LDS stage (a stage is
+// read by both row groups before the loader may refill it, i.e. one barrier interval later than with two phases).
+template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST, int PH = 2>
 __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
   constexpr int TM = BM / 32, TN = BN / 64, RB = TM / 2;
   constexpr int SAL = BM / 32, SBL = BN / 32;          // 1 KB pieces per loader wave and operand tile
   constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
   static_assert(NST == 2 || NST == 3, "two or three LDS stages");
+  static_assert(PH == 2 || (PH == 1 && NST == 3), "one phase per k-tile needs three stages");
   static_assert(BM % 64 == 0 && BN % 64 == 0 && SAL % 2 == 0 && SBL % 2 == 0, "tile shape");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), i = lane & 15, g = lane >> 4;
@@ -85,9 +91,12 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
       }                                                                                                                               \
     }                                                                                                                                 \
   } while (0)
-    // prologue: k-tile 0 complete; behind it B(1) [two stages] or A(1), B(1), B(2) [three]
+    // prologue: k-tile 0 complete; behind it B(1) [two stages] or A(1), B(1), B(2) [three] or k-tile 1 [one phase per k-tile]
     SAM_LDMA_A(0); SAM_LDMA_A(1); SAM_LDMA_B(0); SAM_LDMA_B(1);
-    if constexpr (NST == 2) {
+    if constexpr (PH == 1) {
+      if (total > 1) { SAM_LDMA_A(0); SAM_LDMA_A(1); SAM_LDMA_B(0); SAM_LDMA_B(1); vmwait<SAL + SBL>(); }
+      else vmwait<0>();
+    } else if constexpr (NST == 2) {
       if (total > 1) { SAM_LDMA_B(0); SAM_LDMA_B(1); vmwait<SBL>(); }
       else vmwait<0>();
     } else {
@@ -97,6 +106,20 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
     }
     __builtin_amdgcn_s_barrier();
     int kt = 0;
+    if constexpr (PH == 1) {
+      // two intervals per k-tile (upper group: reads of k-tile u | its MFMAs; the lower group one barrier behind): k-tile u+2 goes out, A in the first interval and
+      // B in the second, into the stage k-tile u-1 was read from -- by the lower group one interval ago --, then k-tile u+1 must have landed
+      for (int u = 0; u < total; ++u) {
+        const bool issue = ua < total;
+        if (issue) { SAM_LDMA_A(0); SAM_LDMA_A(1); }
+        __builtin_amdgcn_s_barrier();
+        if (issue) { SAM_LDMA_B(0); SAM_LDMA_B(1); vmwait<SAL + SBL>(); }
+        else vmwait<0>();
+        __builtin_amdgcn_s_barrier();
+        if (++kt == KT) { kt = 0; __builtin_amdgcn_s_barrier(); }
+      }
+      return;
+    }
     for (int u = 0; u < total; ++u) {
       // interval 1 / 2 (upper group: reads of phase 0, MFMAs of phase 0): A of k-tile u+1 [u+2 with three stages] -- its stage was last read in phase 1 of
       // k-tile u-1, by the lower group one barrier ago
@@ -137,12 +160,37 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
   if (wr == 1) __builtin_amdgcn_s_barrier();      // lower row group: one barrier behind from here on
 
   const int sig = ((i >> 3) & 1) | ((g & 1) << 1);
-  bf16x8 af[RB][2], bfr[TN][2];
+  constexpr int AFR = PH == 1 ? TM : RB;
+  bf16x8 af[AFR][2], bfr[TN][2];
   int kt = 0, j = 0, su = 0;
   for (int u = 0; u < total; ++u) {
     const unsigned char* stA = smem + su * STAGE;
     const unsigned char* stB = stA + A_BYTES;
     su = su + 1 == NST ? 0 : su + 1;
+    if constexpr (PH == 1) {
+      // ---- the whole k-tile: every fragment, then every MFMA
+#pragma unroll
+      for (int x = 0; x < TN; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) bfr[x][ks] = frag<BKC>(stB, wc * (BN / 4) + x * 16, ks, i, g, sig);
+#pragma unroll
+      for (int x = 0; x < AFR; ++x)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[x][ks] = frag<AKC>(stA, wr * (BM / 2) + x * 16, ks, i, g, sig);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int x = 0; x < AFR; ++x)
+#pragma unroll
+          for (int y = 0; y < TN; ++y) acc[y][x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[y][ks], af[x][ks], acc[y][x], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    } else {
     // ---- phase 0: all B fragments + upper A rows
 #pragma unroll
     for (int x = 0; x < TN; ++x)
@@ -183,6 +231,7 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    }
     // ---- end of a tile: epilogue.  Its stores are NOT waited for: the operand queue belongs to the loader waves, this wave's next counted wait is its own
     // epilogue's operand prefetch one tile later
     if (++kt == KT) {
@@ -213,18 +262,18 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
   }
 }
 
-template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST>
+template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST, int PH = 2>
 int launch12(GemmArgs a, int n_cu, hipStream_t st) {
   constexpr size_t LDS = (size_t)NST * (BM + BN) * 128;
   static_assert(LDS <= 160 * 1024, "LDS stages");
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm12_kernel<BM, BN, AKC, BKC, EPI, OutT, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm12_kernel<BM, BN, AKC, BKC, EPI, OutT, NST, PH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     once = true;
   }
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int tiles = a.tiles_m * a.tiles_n;
-  gemm12_kernel<BM, BN, AKC, BKC, EPI, OutT, NST><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), LDS, st>>>(a);
+  gemm12_kernel<BM, BN, AKC, BKC, EPI, OutT, NST, PH><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), LDS, st>>>(a);
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }
@@ -236,7 +285,10 @@ int pick12(const GemmArgs& a, int tile, hipStream_t st) {
   const int t256 = ((a.M + 191) / 192) * ((a.N + 255) / 256);
   const bool wide = tile == 12448 || (tile != 12192 && a.N % 256 == 0 && t256 >= 2 * n_cu + n_cu / 2);
   if (wide) return launch12<192, 256, true, BKC, EPI, bf16_t, 2>(a, n_cu, st);
-  return launch12<192, 192, true, BKC, EPI, bf16_t, 3>(a, n_cu, st);
+  static int ph = -1;
+  if (ph < 0) { const char* v = getenv("SAM_GEMM12_PHASES"); ph = v ? atoi(v) : 1; }          // (2: the two-phase schedule, for an A/B)
+  if (ph == 2) return launch12<192, 192, true, BKC, EPI, bf16_t, 3, 2>(a, n_cu, st);
+  return launch12<192, 192, true, BKC, EPI, bf16_t, 3, 1>(a, n_cu, st);
 }
 
 }  // namespace
