@@ -433,7 +433,7 @@ def encoder_only(batch_size, dev, n_spatial=4, shape=(0, 100, 50, 12), steps=12,
                 mfma_fraction=round(batch_size * steps / dt * gf * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4))
 
 
-def eval_decode(context, layers, vocab, shape, batch_size, dev, reps=6, warmup=3):
+def eval_decode(context, layers, vocab, shape, batch_size, dev, reps=6, warmup=3, modes=("greedy", "beam5")):
     """evaluation-time decoding of one batch (greedy: sa_m4c.py:285-302; beam 5: sam/beam_search.py) through the captured decode session"""
     from sam_textvqa_amd.params import prepare
     from sam_textvqa_amd.registry import registry
@@ -451,6 +451,8 @@ def eval_decode(context, layers, vocab, shape, batch_size, dev, reps=6, warmup=3
     out = {}
     with torch.no_grad():
         for name, fn in (("greedy", lambda: model(clone_batch(batch))), ("beam5", beam)):
+            if name not in modes:
+                continue
             for _ in range(warmup):
                 fn()
             torch.cuda.synchronize()
@@ -683,6 +685,9 @@ def main():
                             **encoder_only(64, dev)))
             res["secondary"] = sec
             res["eval_decode"] = eval_decode(args.context, layers, args.vocab, shape, args.batch, dev)
+            if args.shape == "c3":
+                res["eval_decode_stress"] = dict(workload="greedy decoding at the stress shape: 350 tokens, 100 OCR slots, 30 steps, 12 layers (n,n,s x10), B=32",
+                                                 **eval_decode(3, ("n", "n") + ("s",) * 10, args.vocab, SHAPES["stress"], 32, dev, reps=4, warmup=2, modes=("greedy",)))
         except Exception as e:          # never lose the headline over a secondary row
             res["secondary"] = sec + [{"error": "%s: %s" % (type(e).__name__, str(e)[:200])}]
         res["data_parallel_1rank"] = dist_one_rank(args)

@@ -370,7 +370,7 @@ int sam_beam_step_split(const float* fixed_scores, int64_t ld_fixed, const float
  *   wc bf16 [V -> multiple of 16, D] and wq bf16 [D, D], both fragment-tiled as above; bc, bq fp32; ptr_k bf16 [B, No, D] the pointer network's keys; ocr_mask u8 [B, No]; ptr_scale = 1/sqrt(D);
  *   prev_inds int64 [B, S]; fixed_scores fp32 [B, S, ld_fixed], ocr_scores fp32 [B, S, No]; seq_out (may be NULL) bf16 [B, N, D] receives the final
  *     hidden state of row n_enc + t.
- * Built for D = 768, F = 3072, head_dim 64, N <= 256, No <= 64, <= 8 layers: anything else returns SAM_ERR_UNSUPPORTED (callers fall back to the
+ * Built for D = 768, F = 3072, head_dim 64, N <= 384 (caches past 256 rows take the keys in two chunks of 192 with a running maximum), No <= 128, <= 12 layers: anything else returns SAM_ERR_UNSUPPORTED (callers fall back to the
  * per-kernel step).  ws: sam_greedy_decode_ws_bytes(B, S, n_layers) bytes (~100 MB: the activations of every (XCD, step, layer) get their own 16-row
  * slot, see csrc/decode_steps.hip on coherence), 256-byte aligned; int32 word 256 of it (byte 1024) is a sticky error flag, non-zero when
  * a grid barrier timed out.  Zero the whole workspace once after allocation and again after an error: a clean launch leaves the barrier words at zero. */

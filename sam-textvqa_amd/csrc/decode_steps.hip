@@ -41,7 +41,7 @@ extern "C" int sam_attn_words_per_row(int N);
 
 namespace {
 
-constexpr int NT = 256, NW = NT / 64, MAXL = 8, D = 768, F = 3072, HD = 64, KSPLIT = 4, NCH = D / 256, NXCD = 8;
+constexpr int NT = 256, NW = NT / 64, MAXL = 12, MAXNO = 128, D = 768, F = 3072, HD = 64, KSPLIT = 4, NCH = D / 256, NXCD = 8;
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 
 struct Best { float v; int i; };
@@ -336,11 +336,81 @@ __device__ __forceinline__ void attn_finish(const uint4 (&kf)[NI], const uint4 (
   }
 }
 
+// The same task for caches of more than 256 rows (the 350-token shape: 48 key/value chunks per lane would not fit the register file): the keys are
+// taken 8 * NI at a time with a running maximum -- the sum and the accumulators are rescaled when a later chunk raises it (exact in fp32 up to
+// the rounding of one extra multiply, so this path is not bit-identical to the one-pass version and serves only the sizes that one cannot).
+template <int NI>
+__device__ __forceinline__ void attn_chunked(const DArgs& a, const DLayer& L, const Grp& G, int li, int row, int h, int t) {
+  const int lane = threadIdx.x & 63, b = G.b0 + row, kg = lane >> 3, dc = lane & 7;
+  const int qc = a.n_enc + t, nk = qc + 1;
+  const bf16_t* base = L.qkv + (long long)b * a.N * (3 * D) + h * HD + dc * 8;
+  const bf16_t* cur = base + (long long)qc * (3 * D);
+  const uint4 qu = *reinterpret_cast<const uint4*>(cur), kcur = *reinterpret_cast<const uint4*>(cur + D), vcur = *reinterpret_cast<const uint4*>(cur + 2 * D);
+  const uint32_t* ap = L.allow + b * L.allow_sb + h * L.allow_sh + (long long)qc * a.NWORDS;
+  const float q8[8] = {bf_lo(qu.x), bf_hi(qu.x), bf_lo(qu.y), bf_hi(qu.y), bf_lo(qu.z), bf_hi(qu.z), bf_lo(qu.w), bf_hi(qu.w)};
+  float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < nk; k0 += 8 * NI) {                     // (8 NI is a multiple of 32: a chunk starts on an allow word)
+    uint4 kf[NI], vf[NI];
+    uint32_t aw[NI / 4];
+#pragma unroll
+    for (int w = 0; w < NI / 4; ++w) aw[w] = ap[min((k0 >> 5) + w, a.NWORDS - 1)];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const bf16_t* rp = base + (long long)min(k0 + kg + 8 * i, max(qc - 1, 0)) * (3 * D);
+      kf[i] = *reinterpret_cast<const uint4*>(rp + D);
+      vf[i] = *reinterpret_cast<const uint4*>(rp + 2 * D);
+    }
+    float s[NI];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int j = k0 + kg + 8 * i;
+      const uint4 u = j == qc ? kcur : kf[i];
+      float d = q8[0] * bf_lo(u.x);
+      d = fmaf(q8[1], bf_hi(u.x), d); d = fmaf(q8[2], bf_lo(u.y), d); d = fmaf(q8[3], bf_hi(u.y), d);
+      d = fmaf(q8[4], bf_lo(u.z), d); d = fmaf(q8[5], bf_hi(u.z), d); d = fmaf(q8[6], bf_lo(u.w), d); d = fmaf(q8[7], bf_hi(u.w), d);
+      d = sum8(d);
+      const bool valid = j < nk && ((aw[i / 4] >> (j & 31)) & 1u);
+      s[i] = valid ? d * a.scale_log2 : -INFINITY;
+      mx = fmaxf(mx, s[i]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mn = fmaxf(m, mx);
+    const float f = m == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(m - mn);
+    l *= f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] *= f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const float p = s[i] == -INFINITY ? 0.f : __builtin_amdgcn_exp2f(s[i] - mn);
+      l += p;
+      uint4 u = (k0 + kg + 8 * i) == qc ? vcur : vf[i];
+      if (p == 0.f) u = uint4{0u, 0u, 0u, 0u};
+      acc[0] = fmaf(p, bf_lo(u.x), acc[0]); acc[1] = fmaf(p, bf_hi(u.x), acc[1]); acc[2] = fmaf(p, bf_lo(u.y), acc[2]); acc[3] = fmaf(p, bf_hi(u.y), acc[3]);
+      acc[4] = fmaf(p, bf_lo(u.z), acc[4]); acc[5] = fmaf(p, bf_hi(u.z), acc[5]); acc[6] = fmaf(p, bf_lo(u.w), acc[6]); acc[7] = fmaf(p, bf_hi(u.w), acc[7]);
+    }
+    m = mn;
+  }
+#pragma unroll
+  for (int o = 8; o < 64; o <<= 1) {
+    l += __shfl_xor(l, o);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] += __shfl_xor(acc[e], o);
+  }
+  if (kg == 0) {
+    const float inv = l > 0.f ? 1.0f / l : 0.f;
+    uint4 o4;
+    o4.x = pack_bf16x2(acc[0] * inv, acc[1] * inv); o4.y = pack_bf16x2(acc[2] * inv, acc[3] * inv);
+    o4.z = pack_bf16x2(acc[4] * inv, acc[5] * inv); o4.w = pack_bf16x2(acc[6] * inv, acc[7] * inv);
+    *reinterpret_cast<uint4*>(ctxbuf(a, G, t, li) + tiled(row, h * HD + dc * 8)) = o4;
+  }
+}
+
 // pointer scores, argmax, the next token and the next step's input row of local sample `row`: one block
 __device__ __forceinline__ void pick_task(const DArgs& a, const Grp& G, int row, int t, float* lds, Best* red) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, b = G.b0 + row;
   float* qs = lds;            // [D]
-  float* dyn = lds + D;       // [No <= 64]
+  float* dyn = lds + D;       // [No <= MAXNO]
   const rsrc_t pr = rsrc(partbuf(a, G));
   for (int d = tid; d < D; d += NT) {
     const float p = (__uint_as_float(ld4_l2(pr, ((0 * 16 + row) * D + d) * 4)) + __uint_as_float(ld4_l2(pr, ((1 * 16 + row) * D + d) * 4))) +
@@ -355,19 +425,19 @@ __device__ __forceinline__ void pick_task(const DArgs& a, const Grp& G, int row,
 #pragma unroll
   for (int q = 0; q < FPT; ++q) { const int j = tid + q * NT; fv[q] = j < a.V ? __uint_as_float(ld4_l2(fr, j * 4)) : -INFINITY; }
   __syncthreads();
-  {
-    // this wave's OCR keys (o = wave, wave + 4, ...: at most 16 of 64), every row chunk requested before the first dot product
+  for (int o0 = 0; o0 < a.No; o0 += 64) {
+    // this wave's OCR keys of this group of 64 (o = o0 + wave, + 4, ...: at most 16), every row chunk requested before the first dot product
     constexpr int KPW = 64 / NW;
     uint2 kr[KPW][NCH];
 #pragma unroll
     for (int q = 0; q < KPW; ++q) {
-      const bf16_t* kp = a.ptr_k + ((long long)b * a.No + min(wave + q * NW, a.No - 1)) * D;
+      const bf16_t* kp = a.ptr_k + ((long long)b * a.No + min(o0 + wave + q * NW, a.No - 1)) * D;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) kr[q][j] = *reinterpret_cast<const uint2*>(kp + 4 * (lane + 64 * j));
     }
 #pragma unroll
     for (int q = 0; q < KPW; ++q) {
-      const int o = wave + q * NW;
+      const int o = o0 + wave + q * NW;
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < NCH; ++j) {
@@ -409,9 +479,9 @@ __device__ __forceinline__ void pick_task(const DArgs& a, const Grp& G, int row,
   __syncthreads();
 }
 
-template <int NI>
+template <int NI, bool CHUNKED>
 __global__ __launch_bounds__(NT, 1) void decode_steps_kernel(DArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[D + 64];
+  __shared__ __attribute__((aligned(16))) float lds[D + MAXNO];
   __shared__ Best red[NW];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g4 = lane >> 4, li16 = lane & 15;
   // which XCD this block landed on (HW_REG_XCC_ID[3:0]) and its rank among that XCD's blocks (an L2 counter, first come first served).  The
@@ -467,10 +537,14 @@ __global__ __launch_bounds__(NT, 1) void decode_steps_kernel(DArgs a) {
       if (!xcd_sync(a, G, nblk, epoch)) return;
       // A
       for (int task = wg; task < G.nloc * a.H; task += nwaves) {
-        uint4 kf[NI], vf[NI];
-        AttnCur<NI> cur;
-        attn_load<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
-        attn_finish<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
+        if constexpr (CHUNKED) {
+          attn_chunked<NI>(a, L, G, li, task / a.H, task % a.H, t);
+        } else {
+          uint4 kf[NI], vf[NI];
+          AttnCur<NI> cur;
+          attn_load<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
+          attn_finish<NI>(kf, vf, cur, a, L, G, li, task / a.H, task % a.H, t);
+        }
       }
       if (!xcd_sync(a, G, nblk, epoch)) return;
       // O: split-K partials
@@ -554,9 +628,9 @@ extern "C" int64_t sam_greedy_decode_ws_bytes(int B, int S, int n_layers) {
 extern "C" int sam_greedy_decode_steps(const sam_decode_desc* d, void* ws, int64_t ws_bytes, void* stream) {
   SAM_REQUIRE(d && ws && d->layers, "sam_greedy_decode_steps: null pointer");
   const int grid = samgemm::device_cu_count();
-  if (d->D != D || d->F != F || d->H * HD != D || d->n_layers < 1 || d->n_layers > MAXL || d->N > 256 || d->No > 64 || d->B > 16 * NXCD || grid % NXCD != 0) {
-    sam_set_error("sam_greedy_decode_steps: built for D=768, F=3072, head_dim=64, <= %d layers, N <= 256, <= 64 OCR slots, B <= %d, a CU count that is a multiple of 8 "
-                  "(got D=%d F=%d H=%d L=%d N=%d No=%d B=%d CUs=%d)", MAXL, 16 * NXCD, d->D, d->F, d->H, d->n_layers, d->N, d->No, d->B, grid);
+  if (d->D != D || d->F != F || d->H * HD != D || d->n_layers < 1 || d->n_layers > MAXL || d->N > 384 || d->No > MAXNO || d->B > 16 * NXCD || grid % NXCD != 0) {
+    sam_set_error("sam_greedy_decode_steps: built for D=768, F=3072, head_dim=64, <= %d layers, N <= 384, <= %d OCR slots, B <= %d, a CU count that is a multiple of 8 "
+                  "(got D=%d F=%d H=%d L=%d N=%d No=%d B=%d CUs=%d)", MAXL, MAXNO, 16 * NXCD, d->D, d->F, d->H, d->n_layers, d->N, d->No, d->B, grid);
     return SAM_ERR_UNSUPPORTED;
   }
   SAM_REQUIRE(d->B > 0 && d->S >= 1 && d->n_enc >= 0 && d->n_enc + d->S == d->N && d->V > 0 && d->No >= 1, "sam_greedy_decode_steps: bad shape");
@@ -599,8 +673,9 @@ extern "C" int sam_greedy_decode_steps(const sam_decode_desc* d, void* ws, int64
   hipStream_t st = (hipStream_t)stream;
   // (no memset node in front of the kernel: the launch leaves the barrier words at zero itself.  A hipMemsetAsync captured ahead of the kernel
   // left the counter non-zero on graph replays -- barriers fell through, tokens came out wrong)
-  if (d->N <= 192) decode_steps_kernel<24><<<dim3(grid), dim3(NT), 0, st>>>(a);
-  else decode_steps_kernel<32><<<dim3(grid), dim3(NT), 0, st>>>(a);
+  if (d->N <= 192) decode_steps_kernel<24, false><<<dim3(grid), dim3(NT), 0, st>>>(a);
+  else if (d->N <= 256) decode_steps_kernel<32, false><<<dim3(grid), dim3(NT), 0, st>>>(a);
+  else decode_steps_kernel<24, true><<<dim3(grid), dim3(NT), 0, st>>>(a);          // two chunks of 192 keys with a running maximum
   SAM_LAUNCH_CHECK();
   return SAM_OK;
 }

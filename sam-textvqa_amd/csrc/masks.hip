@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void spatial_wave_kernel(const uint32_t* base,
   const int b = row / N, q = row - b * N;
   const int rq = region_of(q, T, n_oo);
   const uint32_t* brow = base + (int64_t)row * NW;
-  for (int c = 0; c * 64 < N; ++c) {                       // 64 keys per pass = two words of every head
+  for (int c = 0; c * 64 < NW * 32; ++c) {                 // 64 keys per pass = two words of every head; ALL NW words of the row are written (the row
+                                                           // stride is 12 words for 257..384 keys: lengths up to 320 leave words 10 and 11 to the padding, which must read 0)
     const int key = c * 64 + lane;
     unsigned bits = 0;                                      // bit h: key visible for head h
     if (key < N) {

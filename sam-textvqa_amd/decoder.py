@@ -316,7 +316,7 @@ class DecodeSession:
             layers.append({"wqkv": None, "bqkv": bqkv, "wo": None, "bo": so.dense.bias.data, "ln1_g": so.LayerNorm.weight.data, "ln1_b": so.LayerNorm.bias.data,
                            "w1": None, "b1": inter.dense.bias.data, "w2": None, "b2": out.dense.bias.data,
                            "ln2_g": out.LayerNorm.weight.data, "ln2_b": out.LayerNorm.bias.data, "qkv": qkv_full, "allow": bits})
-        if not 1 <= len(layers) <= 8 or self.n > 256 or not 1 <= self.n_ocr <= 64:
+        if not 1 <= len(layers) <= 12 or self.n > 384 or not 1 <= self.n_ocr <= 128:
             return False
         pp = mmt.prev_pred_embeddings
         wc, _, bc, _, _, _ = _padded_views(m.classifier.weight, m.classifier.bias)

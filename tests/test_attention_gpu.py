@@ -54,9 +54,11 @@ def oracle_attention(qkv, allow, B, H, scale, keep=None, inv_keep=1.0):
     return ctx, lse
 
 
-@pytest.mark.parametrize("shape", [(3, 20, 100, 50, 12), (2, 4, 10, 6, 3), (2, 20, 200, 100, 30)])
+@pytest.mark.parametrize("shape", [(3, 20, 100, 50, 12), (2, 4, 10, 6, 3), (2, 20, 200, 100, 30), (2, 20, 160, 70, 12), (2, 20, 200, 70, 30), (2, 20, 100, 60, 13)])
 @pytest.mark.parametrize("quadrants", [(1, 2), (4, 7, 8, 9), ()])
 def test_mask_bits_bit_exact(shape, quadrants):
+    """(round 5: 262 and 320 keys -- a 12-word row of which the keys use 9 or 10: the one-wave-per-row spatial packer left words 10 and 11 unwritten
+    there, and the attention kernels read every word of the row; 193 keys for the 8-word stride)"""
     ops = _ops()
     pr = make_problem(*shape, seed=1)
     dev = "cuda"
@@ -65,9 +67,12 @@ def test_mask_bits_bit_exact(shape, quadrants):
     ref_plain = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], None, (), 1)
     assert torch.equal(unpack_bits(base, pr["N"]), ref_plain)
     assert (unpack_bits(base, base.shape[-1] * 32)[..., pr["N"]:] == 0).all()      # keys >= N read 0
+    junk = torch.full((pr["B"] * pr["H"] * pr["N"] * base.shape[-1] + 4096,), -1, dtype=torch.int32, device=dev)      # what the output's allocation held before
+    del junk
     sp = ops.mask_bits_spatial(base, pr["adj"].to(dev), pr["T"], pr["H"], quadrants)
     ref = O.allow_mask(pr["key_valid"], pr["T"], pr["n_oo"], pr["n_dec"], pr["adj"], quadrants, pr["H"])
     assert torch.equal(unpack_bits(sp, pr["N"]), ref)
+    assert (unpack_bits(sp, sp.shape[-1] * 32)[..., pr["N"]:] == 0).all(), "keys >= N must read 0 in every word of the row stride"
     # additive-mask entry point (module-level drop-in API) gives the same base bits
     ext = O.MMT.extended_attention_mask(pr["key_valid"][:, :pr["T"]], pr["key_valid"][:, pr["T"]:pr["T"] + shape[2]],
                                         pr["key_valid"][:, pr["T"] + shape[2]:], pr["n_dec"]).float().contiguous()

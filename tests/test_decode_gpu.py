@@ -633,11 +633,12 @@ def test_beam_search_module_api_mirrors_the_reference():
             break
 
 
-@pytest.mark.parametrize("shapes", [(20, 70, 30, 12), (20, 110, 40, 30), (10, 40, 20, 8)])
+@pytest.mark.parametrize("shapes", [(20, 70, 30, 12), (20, 110, 40, 30), (10, 40, 20, 8), (20, 160, 70, 20), (20, 230, 128, 6)])
 def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatch):
     """the allow masks' row stride is sam_attn_words_per_row(N) = 1, 2, 4, 6, 8 or 12 words, not ceil(N / 32).  The two differ
     for N in (64, 96], (128, 160] and (192, 224]: 132 tokens (6 words, 5 used), 200 tokens (8 words, 7 used) and 78 tokens (4 words, 3 used) must decode
-    like the per-kernel step and like the fp32 oracle"""
+    like the per-kernel step and like the fp32 oracle.  Round 5: 270 tokens with 70 OCR slots (the second chunk of keys holds 78 rows, the second group
+    of OCR slots 6) and the kernel's limits, 384 tokens with 128 OCR slots"""
     from sam_textvqa_amd.params import prepare
     from tests.test_model_gpu import _small_full_model
     model, ref = _small_full_model(3, ("n", "s", "s"), shapes, vocab=300)
@@ -704,8 +705,8 @@ def test_persistent_decoding_kernel_failure_falls_back_to_the_per_kernel_step(mo
 
 
 def test_greedy_decoding_at_the_stress_shape(monkeypatch):
-    """BASELINE configs[4] shapes (350 tokens: 200 obj + 100 OCR + 30 decoding steps): the persistent kernel declines (it is built for <= 256 tokens and
-    <= 64 OCR slots: DecodeSession._fused_plan returns False, nothing raises) and the captured per-kernel step decodes -- compared with the
+    """BASELINE configs[4] shapes (350 tokens: 200 obj + 100 OCR + 30 decoding steps): the persistent kernel takes them (keys in two chunks of 192
+    with a running maximum, 100 OCR slots in two groups of 64) -- compared with the captured per-kernel step (SAM_DECODE_FUSED=0), with the
     reference-style 30 full forwards of the same model and with the fp32 oracle's greedy loop"""
     from sam_textvqa_amd.params import prepare
     from sam_textvqa_amd.synthetic import clone_batch
@@ -715,27 +716,30 @@ def test_greedy_decoding_at_the_stress_shape(monkeypatch):
     model.cuda().eval()
     prepare(model)
     outs = {}
-    for mode in ("full", "session"):
+    for mode in ("full", "perkernel", "session"):
         model.decode_cache = mode != "full"
-        monkeypatch.setenv("SAM_DECODE_SESSION", "1" if mode == "session" else "0")
+        monkeypatch.setenv("SAM_DECODE_SESSION", "0" if mode == "full" else "1")
         monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
-        monkeypatch.setenv("SAM_DECODE_FUSED", "1")
+        monkeypatch.setenv("SAM_DECODE_FUSED", "0" if mode == "perkernel" else "1")
         model.__dict__.pop("_sam_decode_sessions", None)
         bd = _batch(3, shapes, 300, 61, "cuda")
         with torch.no_grad():
             sc = model(bd)["textvqa_scores"]
         outs[mode] = (sc.float().cpu(), bd["train_prev_inds"].cpu())
-        if mode == "session":
+        if mode != "full":
             ses = next(iter(model._sam_decode_sessions.values()))
-            assert ses.fused is False and ses.steps == 30 and ses.n == 350
-    a, b = outs["full"], outs["session"]
+            assert ses.steps == 30 and ses.n == 350
+            assert bool(ses.fused) == (mode == "session"), "the persistent kernel must run the 350-token shape (and only when asked to)"
+    a, b, c = outs["full"], outs["session"], outs["perkernel"]
     live = a[0] > -9000          # (not bit-identical: 90 decoder rows go through other GEMM tiles / split-K than the 1050 rows of a full pass)
     assert torch.equal(a[1], b[1]) and ((a[0] - b[0]).abs()[live].max() / a[0][live].abs().max()).item() < 6e-3
+    assert torch.equal(c[1], b[1]) and ((c[0] - b[0]).abs()[live].max() / c[0][live].abs().max()).item() < 6e-3
     with torch.no_grad():
         want = ref.eval()(clone_batch(_batch(3, shapes, 300, 61, "cpu")))["textvqa_scores"].float()
     live = want > -9000
     err = ((b[0] - want).abs()[live].max() / want[live].abs().max()).item()
-    print("PARITY greedy decode at the stress shape (350 tokens, 30 steps) vs fp32 oracle: scores rel err %.2e, tokens equal %s" % (err, torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:])))
+    print("PARITY greedy decode at the stress shape (350 tokens, 30 steps, persistent kernel) vs fp32 oracle: scores rel err %.2e, tokens equal %s"
+          % (err, torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:])))
     assert err < 1e-2 and torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:])
 
 
