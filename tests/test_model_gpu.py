@@ -153,9 +153,13 @@ def _small_full_model(ctx, layers, shapes, vocab=300, seed=0):
     return model, ref
 
 
-@pytest.mark.parametrize("ctx,layers,shapes", [(3, ("n", "s"), (20, 100, 50, 12)), (5, ("s", "n", "s"), (20, 100, 50, 12))])
+@pytest.mark.parametrize("ctx,layers,shapes", [(3, ("n", "s"), (20, 100, 50, 12)), (5, ("s", "n", "s"), (20, 100, 50, 12)),
+                                               (3, ("n", "s", "s"), (20, 160, 70, 12)), (3, ("s", "n"), (13, 37, 21, 5)), (5, ("s", "s"), (20, 120, 60, 12)),
+                                               (3, ("n", "s"), (7, 20, 9, 3)), (3, ("s", "n"), (20, 200, 70, 30))])
 def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
-    """whole model (input encoders, TextBert, MMT, classifier, pointer net, masked BCE): loss and gradients vs the fp32 oracle"""
+    """whole model (input encoders, TextBert, MMT, classifier, pointer net, masked BCE): loss and gradients vs the fp32 oracle.  Besides the two
+    BASELINE shapes: sequence lengths in every other class of the attention kernels' key tiling and of the masks' row stride (39, 76, 212, 262
+    and 320 tokens -- round 5 found the spatial mask packer wrong for 257..320 keys, which neither BASELINE shape touches)"""
     from sam_textvqa_amd.params import prepare
     from sam_textvqa_amd.synthetic import clone_batch, make_batch
     from sam_textvqa_amd.trainer import masked_bce_loss
@@ -176,7 +180,8 @@ def test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes):
     torch.cuda.synchronize()
     assert tuple(out.shape) == tuple(out_ref.shape)
     within("sam4c scores c=%d" % ctx, score_err(out, out_ref), L["sam4c_scores"])
-    within("sam4c loss c=%d" % ctx, abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), L["sam4c_loss"])
+    # (the loss is a mean over B * n_dec * (vocab + n_ocr) scores: the two 3- and 5-step shapes average a quarter / a half of the terms of the 12-step ones)
+    within("sam4c loss c=%d" % ctx, abs(loss.item() - loss_ref.item()) / abs(loss_ref.item()), L["sam4c_loss"] * (4 if shapes[3] < 12 else 1))
     # padded OCR columns carry the literal -10000 (sa_m4c.py:893)
     pad = (bd_cpu["pad_ocr_mask"] == 0)
     assert (out.cpu()[:, :, 300:][pad.unsqueeze(1).expand(-1, out.shape[1], -1)] < -9000).all()
