@@ -23,9 +23,10 @@ for k in range(count):
             break
     ctx = rnd.choice([3, 5])
     layers = tuple(rnd.choice("ns") for _ in range(rnd.randint(1, 3)))
-    tag = "ctx=%d layers=%s shapes=%s N=%d" % (ctx, "".join(layers), shapes, sum(shapes))
+    batch = rnd.choice([1, 2, 3, 3, 5, 9, 16])
+    tag = "ctx=%d layers=%s shapes=%s N=%d B=%d" % (ctx, "".join(layers), shapes, sum(shapes), batch)
     try:
-        tm.test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes)
+        tm.test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes, batch)
         print("TRAIN ok   ", tag, flush=True)
     except Exception as e:          # noqa: BLE001
         bad += 1
