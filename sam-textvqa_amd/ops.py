@@ -280,7 +280,7 @@ def gemm(a, b, *, a_kcontig=True, b_kcontig=True, m=None, n=None, k=None, out=No
     d.ld_aux = aux.stride(0) if aux is not None else 0
     d.p_drop, d.seed, d.offset = float(p_drop), int(seed), int(offset)
     wgrad_split = bool(accumulate) and out.dtype == torch.float32 and epilogue == capi.EPI_NONE      # partials reduced INTO C by sam_gemm_splitk_reduce
-    if split_k == 0 and not accumulate and force_tile == 0 and M <= 4096 and K >= 1536 and M * N <= (4 << 20):
+    if split_k == 0 and not accumulate and bias_grad is None and force_tile == 0 and M <= 4096 and K >= 1536 and M * N <= (4 << 20):
         split_k = -1       # skinny problem with a long K (TextBert's 20 tokens/sample, classifier dgrad): let the library split K and fold
                            # the epilogue into the partial-sum reduction (it declines when the grid already fills the chip)
     d.split_k, d.bias_grad, d.force_tile = int(split_k), _dp(bias_grad), int(force_tile)
