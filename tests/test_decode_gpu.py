@@ -634,14 +634,14 @@ def test_beam_search_module_api_mirrors_the_reference():
 
 
 @pytest.mark.parametrize("shapes", [(20, 70, 30, 12), (20, 110, 40, 30), (10, 40, 20, 8), (20, 160, 70, 20), (20, 230, 128, 6)])
-def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatch):
+def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatch, vocab=300):
     """the allow masks' row stride is sam_attn_words_per_row(N) = 1, 2, 4, 6, 8 or 12 words, not ceil(N / 32).  The two differ
     for N in (64, 96], (128, 160] and (192, 224]: 132 tokens (6 words, 5 used), 200 tokens (8 words, 7 used) and 78 tokens (4 words, 3 used) must decode
     like the per-kernel step and like the fp32 oracle.  Round 5: 270 tokens with 70 OCR slots (the second chunk of keys holds 78 rows, the second group
     of OCR slots 6) and the kernel's limits, 384 tokens with 128 OCR slots"""
     from sam_textvqa_amd.params import prepare
     from tests.test_model_gpu import _small_full_model
-    model, ref = _small_full_model(3, ("n", "s", "s"), shapes, vocab=300)
+    model, ref = _small_full_model(3, ("n", "s", "s"), shapes, vocab=vocab)
     model.cuda().eval()
     prepare(model)
     model.decode_cache = True
@@ -650,7 +650,7 @@ def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatc
         monkeypatch.setenv("SAM_DECODE_FUSED", fused)
         monkeypatch.setenv("SAM_DECODE_GRAPH", "1")
         model.__dict__.pop("_sam_decode_sessions", None)
-        bd = _batch(5, shapes, 300, 41, "cuda")
+        bd = _batch(5, shapes, vocab, 41, "cuda")
         with torch.no_grad():
             sc = model(bd)["textvqa_scores"]
         outs[fused] = (sc.float().cpu(), bd["train_prev_inds"].cpu())
@@ -662,7 +662,7 @@ def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatc
     assert torch.equal(a[1], b[1]) and err < 6e-3, (sum(shapes), err)
     from sam_textvqa_amd.synthetic import clone_batch
     with torch.no_grad():
-        want = ref.eval()(clone_batch(_batch(5, shapes, 300, 41, "cpu")))["textvqa_scores"].float()
+        want = ref.eval()(clone_batch(_batch(5, shapes, vocab, 41, "cpu")))["textvqa_scores"].float()
     live = want > -9000
     e2 = ((b[0] - want).abs()[live].max() / want[live].abs().max()).item()
     assert e2 < 6e-3 and torch.equal(want.argmax(-1)[:, :-1], b[1][:, 1:]), (sum(shapes), e2)

@@ -24,9 +24,10 @@ for k in range(count):
     ctx = rnd.choice([3, 5])
     layers = tuple(rnd.choice("ns") for _ in range(rnd.randint(1, 3)))
     batch = rnd.choice([1, 2, 3, 3, 5, 9, 16])
-    tag = "ctx=%d layers=%s shapes=%s N=%d B=%d" % (ctx, "".join(layers), shapes, sum(shapes), batch)
+    vocab = rnd.choice([300, 300, 77, 1000, 5000, 4999, 16])
+    tag = "ctx=%d layers=%s shapes=%s N=%d B=%d V=%d" % (ctx, "".join(layers), shapes, sum(shapes), batch, vocab)
     try:
-        tm.test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes, batch)
+        tm.test_sam4c_train_forward_backward_vs_oracle(ctx, layers, shapes, batch, vocab)
         print("TRAIN ok   ", tag, flush=True)
     except Exception as e:          # noqa: BLE001
         bad += 1
@@ -34,7 +35,7 @@ for k in range(count):
     if n_dec >= 2 and shapes[2] >= 1:
         mp = pytest.MonkeyPatch()
         try:
-            td.test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, mp)
+            td.test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, mp, vocab)
             print("DECODE ok  ", tag, flush=True)
         except Exception as e:      # noqa: BLE001
             bad += 1
