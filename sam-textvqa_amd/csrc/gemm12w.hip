@@ -179,26 +179,41 @@ __global__ __launch_bounds__(768, 3) void gemm12w_kernel(WArgs w) {
     left = cur.nkt;
     // Bias gradient = column sums of dy = sum over k of the A tile, taken HERE: the loader waves are idle most of a k-tile, the A tile is in LDS anyway, and
     // the compute waves have no register to spare (an accumulator and a selector operand for a 25th MFMA put them over 168 and into scratch inside the loop).
-    // Loader lw owns columns [48 lw, 48 lw + 48) of the tile's 192 (six 16-byte chunks of the k-strided image); lane = k-row: 48 running sums per lane, one wave
-    // reduction per column when the item ends.  Only tiles of a problem's first tile column carry it.
-    float bs[48];
+    // Loader lw owns the three 16-column fragment rows [48 lw, 48 lw + 48) of the tile's 192 and sums them on the MATRIX pipe: D = ones x A^T, six MFMAs per k-tile
+    // (lane (i, g) ends up with the sum of column 16 x + i in every register of accb[x]).  (The first version summed on the VALU -- 6 ds_read_b128 + ~100
+    // unpack / add instructions per k-tile: the CUs whose tile carries a bias gradient ran 16 % slower and set the launch's time: 341 -> 428 us per layer pair.)
+    // Only tiles of a problem's first tile column carry it.
+    f32x4 accb[3];
 #pragma unroll
-    for (int c = 0; c < 48; ++c) bs[c] = 0.f;
+    for (int x = 0; x < 3; ++x) accb[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (bf16_t)0x3F80;
+    const int bi = lane & 15, bg = lane >> 4, bsig = ((bi >> 3) & 1) | ((bg & 1) << 1);
+    bf16x8 fa[3][2];
+    bool pend = false;
     bool cbias = cur.P.bias_grad != nullptr && cur.n0 == 0;
     for (;;) {
       const bool issue_a = va;
       if (issue_a) SAM_LDMA_A(0);
       __builtin_amdgcn_s_barrier();
       if (issue_a) SAM_LDMA_A(1);
+      // the bias gradient's fragments of THIS k-tile are requested here and multiplied one k-tile later (at the item's end for the last one): the loader never waits
+      // for an LDS read in front of a barrier.  (Measured per layer pair with bias gradients, 339 us without: VALU sums 428; MFMAs right behind the reads, all in
+      // this interval 394, half of them in the interval before 464.)
       if (cbias) {
+        if (pend) {
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int x = 0; x < 3; ++x) accb[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[x][ks], accb[x], 0, 0, 0);
+        }
         const unsigned char* stA = smem + su * STAGE;
 #pragma unroll
-        for (int cc = 0; cc < 6; ++cc) {
-          const int ch = 6 * lw + cc, panel = ch >> 3, c = ch & 7;
-          const uint4 v = *reinterpret_cast<const uint4*>(stA + panel * 8192 + lane * 128 + ((c ^ (ks_sigma(lane) << 1)) << 4));
-          bs[8 * cc + 0] += bf_lo(v.x); bs[8 * cc + 1] += bf_hi(v.x); bs[8 * cc + 2] += bf_lo(v.y); bs[8 * cc + 3] += bf_hi(v.y);
-          bs[8 * cc + 4] += bf_lo(v.z); bs[8 * cc + 5] += bf_hi(v.z); bs[8 * cc + 6] += bf_lo(v.w); bs[8 * cc + 7] += bf_hi(v.w);
-        }
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks) fa[x][ks] = frag<false>(stA, (3 * lw + x) * 16, ks, bi, bg, bsig);
+        pend = true;
       }
       su ^= 1;
       __builtin_amdgcn_s_barrier();
@@ -211,13 +226,20 @@ __global__ __launch_bounds__(768, 3) void gemm12w_kernel(WArgs w) {
       if (--left == 0) {
         __builtin_amdgcn_s_barrier();        // the upper group's alignment barrier at an item's end
         if (cbias) {
-          // column c of this loader's 48: the wave sum of bs[c], kept by lane c
+          if (pend) {          // the last k-tile's fragments
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+              for (int x = 0; x < 3; ++x) accb[x] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[x][ks], accb[x], 0, 0, 0);
+            pend = false;
+          }
+          // column c = 16 x + i of this loader's 48 is in lane i of accb[x]: lane c takes it
           float mine = 0.f;
 #pragma unroll
-          for (int c = 0; c < 48; ++c) {
-            const float t = wave_sum(bs[c]);
-            if (lane == c) mine = t;
-            bs[c] = 0.f;
+          for (int x = 0; x < 3; ++x) {
+            const float t = __shfl(accb[x][0], lane & 15);
+            if ((lane >> 4) == x) mine = t;
+            accb[x] = f32x4{0.f, 0.f, 0.f, 0.f};
           }
           const int m = cur.m0 + 48 * lw + lane;
           if (cur.kind == 0) {
