@@ -28,7 +28,7 @@ constexpr int SAL = BM / 32, SBL = BN / 32;                        // 1 KB DMA p
 constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES, NST = 2;
 constexpr int FRAGS = TM * TN;                                      // 24
 constexpr int SLOT_FLOATS = FRAGS * 8 * 64 * 4 + BM;                // a workgroup's accumulators, lane-linear, + its 192 bias-gradient partials
-constexpr int MAXP = samgemm::SAM_MAX_GROUP8;
+constexpr int MAXP = samgemm::SAM_MAX_GROUP8, MAXG = 320;          // MAXG: workgroups (= CUs) of a launch
 
 struct WProb {
   const bf16_t* A; int64_t lda;      // dy [K rows, M]
@@ -43,6 +43,9 @@ struct WArgs {
   int count, dbg;
   int n_deep, n_total;               // tiles of the deepest problems (all of one K) / all tiles
   int rounds1, R, S, kt_deep;        // whole-tile rounds of the deep tiles, tiles left over, slices per left-over tile, k-tiles of a deep tile
+  short slice_of[MAXG];              // block -> tl + R * sl of its K slice in round `rounds1`, -1: none (the block goes straight on to the shallow tiles).  Blocks whose
+                                     // whole tiles carried a bias gradient get none when the rest can take all slices: their loader waves' extra work made them
+                                     // ~15 % slower per k-tile, about the length of a slice -- they finish level with the others (experiment 13)
   float* slots;                      // [R][S] x SLOT_FLOATS
   unsigned* cnt;                     // [R][8 waves][2] arrive / done, then [R][4 loader waves] bias arrivals; zero between launches
   unsigned* err;                     // error word of the workspace
@@ -70,11 +73,12 @@ __device__ __forceinline__ WProb load_prob(WPtr wp, int q) {
 __device__ __forceinline__ bool get_item(WPtr wp, const WArgs& w, int j, int b, int G, Item& it) {
   int gt;
   it.kind = 0; it.tl = 0; it.sl = 0;
+  const int e = w.R > 0 ? (int)wp->slice_of[b] : -1;
+  if (w.R > 0 && e < 0 && j >= w.rounds1) ++j;          // no slice for this block: its item sequence skips the slice round
   if (j < w.rounds1) {
     gt = j * G + (b % 8) * (G / 8) + b / 8;
   } else if (w.R > 0 && j == w.rounds1) {
-    if ((w.R & 7) == 0) { const int rpx = w.R / 8, loc = b / 8; it.tl = (b % 8) * rpx + loc % rpx; it.sl = loc / rpx; }
-    else { it.tl = b % w.R; it.sl = b / w.R; }
+    it.tl = e % w.R; it.sl = e / w.R;
     it.kind = 1;
     gt = w.rounds1 * G + it.tl;
   } else {
@@ -415,41 +419,86 @@ namespace samgemm {
 // workspace of the slice exchange for a set with `r` left-over tiles of `s` slices: [64 words: word 0 = error][counters, padded to 64 words][slots]
 static int64_t ws12_bytes(int r, int s) { return (int64_t)r * s * SLOT_FLOATS * 4 + (int64_t)(64 + ((r * 20 + 63) / 64) * 64) * 4 + 256; }
 
-// the schedule of a problem set on `n_cu` CUs; false: not a set for this kernel
-static bool plan12(const sam_gemm_desc* descs, int count, int n_cu, int* order, int& n_deep, int& n_total, int& rounds1, int& R, int& S, int& kt_deep) {
-  if (count < 1 || count > MAXP || n_cu % 8 != 0) return false;
+// the schedule of a problem set on `n_cu` CUs; false: not a set for this kernel.  slice_of (may be NULL): the block -> slice table of WArgs; S_ws: the largest
+// slice count any table for this set may use (sizes the workspace: the bias-aware table depends on which problems carry a bias gradient at launch time)
+static bool plan12(const sam_gemm_desc* descs, int count, int n_cu, int* order, int& n_deep, int& n_total, int& rounds1, int& R, int& S, int& kt_deep, short* slice_of,
+                   int& S_ws) {
+  if (count < 1 || count > MAXP || n_cu % 8 != 0 || n_cu > MAXG) return false;
   int max_k = 0;
   for (int q = 0; q < count; ++q) { order[q] = q; max_k = descs[q].K > max_k ? descs[q].K : max_k; }
   for (int a = 1; a < count; ++a)
     for (int b = a; b > 0 && descs[order[b]].K > descs[order[b - 1]].K; --b) { const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t; }
   n_deep = n_total = 0;
+  int tstart[MAXP + 1];
   for (int q = 0; q < count; ++q) {
     const sam_gemm_desc* d = descs + order[q];
     if (d->K % BK != 0 || d->K < BK || d->M % 8 != 0 || d->N % 8 != 0) return false;
     if ((int64_t)d->K * d->lda * 2 >= (int64_t)0x7fffffff || (int64_t)d->K * d->ldb * 2 >= (int64_t)0x7fffffff) return false;
     const int t = ((d->M + BM - 1) / BM) * ((d->N + BN - 1) / BN);
+    tstart[q] = n_total;
     n_total += t;
     if (d->K == max_k) n_deep += t;
   }
+  tstart[count] = n_total;
   kt_deep = max_k / BK;
   rounds1 = n_deep / n_cu;
   R = n_deep - rounds1 * n_cu;
-  S = 0;
+  S = S_ws = 0;
   if (rounds1 < 1) return false;                              // fewer deep tiles than CUs: the pair-exchange kernel (gemm8w.hip) does better
-  if (R > 0) {
-    if (n_cu % R != 0) return false;
-    S = n_cu / R;
-    const int per = (kt_deep + S - 1) / S;
-    if (S < 2 || S > FRAGS || kt_deep < 2 * S || (S - 1) * per >= kt_deep) return false;      // (every slice needs at least one k-tile)
-  }
   if (n_total > 16 * n_cu) return false;
+  if (R == 0) return true;
+  auto valid = [&](int s_) { const int per = (kt_deep + s_ - 1) / s_; return s_ >= 2 && s_ <= FRAGS && kt_deep >= 2 * s_ && (s_ - 1) * per < kt_deep; };   // (every slice needs a k-tile)
+  if (n_cu % R != 0) return false;
+  S = S_ws = n_cu / R;
+  if (!valid(S)) return false;
+  if (!slice_of) return true;
+  // every block takes a slice: XCD x gets R / 8 of the left-over tiles with all their slices (tiles next to each other share operand panels slice by slice)
+  const bool by_xcd = (R & 7) == 0;
+  const int rpx = R / 8;
+  for (int b = 0; b < n_cu; ++b) {
+    const int xcd = b % 8, loc = b / 8;
+    const int tl = by_xcd ? xcd * rpx + loc % rpx : b % R, sl = by_xcd ? loc / rpx : b / R;
+    slice_of[b] = (short)(tl + R * sl);
+  }
+  // bias-aware table: which blocks' whole tiles carry a bias gradient (the tile walk of get_item, rounds 0 .. rounds1 - 1)
+  static int aware = -1;
+  if (aware < 0) { const char* e = getenv("SAM_GEMM12W_BIAS_AWARE"); aware = e ? atoi(e) : 1; }
+  if (!aware || !by_xcd) return true;
+  bool has_bias[MAXG];
+  int free_x[8] = {0, 0, 0, 0, 0, 0, 0, 0}, n_bias = 0;
+  for (int b = 0; b < n_cu; ++b) {
+    has_bias[b] = false;
+    for (int j = 0; j < rounds1; ++j) {
+      const int gt = j * n_cu + (b % 8) * (n_cu / 8) + b / 8;
+      int pi = 0;
+      for (int q = 1; q < count; ++q)
+        if (gt >= tstart[q]) pi = q;
+      const sam_gemm_desc* d = descs + order[pi];
+      const int tm = (d->M + BM - 1) / BM, tn = (d->N + BN - 1) / BN, tile = gt - tstart[pi];
+      const int n0 = (tn > tm ? tile / tm : tile % tn) * BN;
+      if (d->bias_grad && n0 == 0) has_bias[b] = true;
+    }
+    if (has_bias[b]) ++n_bias; else ++free_x[b % 8];
+  }
+  int s2 = FRAGS;
+  for (int x = 0; x < 8; ++x) s2 = free_x[x] / rpx < s2 ? free_x[x] / rpx : s2;
+  // worth it when a slice stays about as long as what the bias gradient costs a block (~15 % of a tile): at least five slices per tile
+  if (n_bias == 0 || s2 < 5 || s2 >= S || !valid(s2)) return true;
+  int k_x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < n_cu; ++b) {
+    const int xcd = b % 8;
+    if (has_bias[b] || k_x[xcd] >= rpx * s2) { slice_of[b] = -1; continue; }
+    const int k = k_x[xcd]++;
+    slice_of[b] = (short)(xcd * rpx + k % rpx + R * (k / rpx));
+  }
+  S = s2;
   return true;
 }
 
 int64_t gemm12w_ws_bytes(const sam_gemm_desc* descs, int count) {
-  int order[MAXP], n_deep, n_total, rounds1, R, S, ktd;
-  if (!plan12(descs, count, device_cu_count(), order, n_deep, n_total, rounds1, R, S, ktd) || R == 0) return 0;
-  return ws12_bytes(R, S);
+  int order[MAXP], n_deep, n_total, rounds1, R, S, ktd, s_ws;
+  if (!plan12(descs, count, device_cu_count(), order, n_deep, n_total, rounds1, R, S, ktd, nullptr, s_ws) || R == 0) return 0;
+  return ws12_bytes(R, s_ws);
 }
 
 // returns SAM_ERR_UNSUPPORTED when the set is not one for this kernel (the caller goes on to gemm8w_grouped / the 4-wave kernel)
@@ -457,7 +506,8 @@ int gemm12w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   const int n_cu = device_cu_count();
   int order[MAXP];
   WArgs w = {};
-  if (!plan12(descs, count, n_cu, order, w.n_deep, w.n_total, w.rounds1, w.R, w.S, w.kt_deep)) return SAM_ERR_UNSUPPORTED;
+  int s_ws = 0;
+  if (!plan12(descs, count, n_cu, order, w.n_deep, w.n_total, w.rounds1, w.R, w.S, w.kt_deep, w.slice_of, s_ws)) return SAM_ERR_UNSUPPORTED;
   w.count = count;
   int tiles = 0;
   for (int q = 0; q < count; ++q) {
@@ -474,7 +524,7 @@ int gemm12w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
   if (!d0->ws || ((uintptr_t)d0->ws % 16) != 0) return SAM_ERR_UNSUPPORTED;
   w.err = reinterpret_cast<unsigned*>(d0->ws);
   if (w.R > 0) {
-    if (d0->ws_bytes < ws12_bytes(w.R, w.S)) return SAM_ERR_UNSUPPORTED;
+    if (d0->ws_bytes < ws12_bytes(w.R, s_ws)) return SAM_ERR_UNSUPPORTED;
     w.cnt = reinterpret_cast<unsigned*>(d0->ws) + 64;                                   // zero between launches (the caller zero-fills once)
     w.slots = d0->ws + 64 + ((w.R * 20 + 63) / 64) * 64;
   }
