@@ -564,6 +564,16 @@ def main():
                 torch._foreach_copy_([bd[k] for k in src], list(src.values()))
         return bd
 
+    # host-side preparation (events, a full collection) BEFORE the warm-up steps, so that the GPU goes from the last warm-up step into the timed region with nothing but
+    # a synchronize in between: a generation-2 collection over the model's object graph is a 20-50 ms host pause, and a timed region that started right after one
+    # has twice shown a single 25-31 ms step at index 1 or 2 (GPU time between events, host call 0.8 ms: the device, not the host, stalled -- `slow_steps`).
+    import gc
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    # the cyclic collector stays off from here to the end of the timed region (a generation-2 pass is a 10-20 ms host pause, i.e. two or three steps of an idle GPU
+    # once every few hundred steps); a training loop does the same with gc.freeze()
+    gc.disable()
     for j in range(args.warmup):
         loss = trainer.step(next_batch(j, batch) if j else clone_batch(batch))
     torch.cuda.synchronize()
@@ -578,15 +588,8 @@ def main():
         one = torch.ones(1, dtype=torch.float32, device=dev)
         parallel.dist.all_reduce(one, group=trainer.reducer.group if trainer.reducer is not None else None)
         ranks_seen = int(round(one.item()))
-    # host-side preparation (events, a full collection) BEFORE the bracket, so that nothing sits between the synchronize and the first launch.  (The first timed
-    # step still reads ~7.0 ms against 6.1: its event bracket contains the ~1 ms the host needs to submit the first graph to an idle GPU; steps 1-3 read 6.4 / 6.25 / 6.2.)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    # the cyclic collector stays off inside the timed region (a generation-2 pass over the model's object graph is a 10-20 ms host pause, i.e. two or three
-    # steps of an idle GPU once every few hundred steps: seen as single 20 ms steps in `slow_steps`); a training loop does the same with gc.freeze()
-    import gc
-    gc.collect()
-    gc_was_on = gc.isenabled()
-    gc.disable()
+    # (The first timed step still reads ~7.0 ms against 6.1: its event bracket contains the ~1 ms the host needs to submit the first graph to an idle GPU; steps 1-3 read
+    # 6.4 / 6.25 / 6.2.)
     if parallel.dist.is_initialized():
         parallel.dist.barrier()
     torch.cuda.synchronize()
