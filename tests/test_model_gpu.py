@@ -636,20 +636,20 @@ def test_rccl_path_one_rank_matches_plain_trainer(tmp_path, three_groups):
     run_child([sys.executable, "-c", _DIST_SCRIPT], env, "DIST_OK", "rccl_one_rank_%s" % ("three_groups" if three_groups else "two_groups"))
 
 
-def test_training_trajectory_matches_oracle_train_step():
+def test_training_trajectory_matches_oracle_train_step(shapes=(20, 100, 50, 12), layers=("n", "s"), ctx=3, batch=3):
     """SURVEY §8a a-18 end to end: six optimisation steps (forward, masked BCE, backward, clip 0.25, Adam, LambdaLR warm-up) of the HIP
-    Trainer against the oracle's train_step (train.py:133-144 restated) from identical weights on identical batches, dropout off"""
+    Trainer against the oracle's train_step (train.py:133-144 restated) from identical weights on identical batches, dropout off.
+    (The arguments are for tools/fuzz_shapes.py, which calls this with random shapes.)"""
     from sam_textvqa_amd.synthetic import clone_batch, make_batch
     from sam_textvqa_amd.trainer import Trainer
-    shapes = (20, 100, 50, 12)
-    model, ref = _small_full_model(3, ("n", "s"), shapes)
+    model, ref = _small_full_model(ctx, layers, shapes)
     init = {k: v.clone() for k, v in ref.state_dict().items()}
     tr = Trainer(model, base_lr=1e-3, seed=3)
     opt, sched = O.make_optimizer(ref, base_lr=1e-3)
     ref.train()
     batches = []
     for i in range(3):
-        bd = make_batch(3, *shapes, vocab=300, context=3, device="cpu", seed=40 + i)
+        bd = make_batch(batch, *shapes, vocab=300, context=ctx, device="cpu", seed=40 + i)
         bd["question_indices"] = (bd["question_indices"] % 499 + 1) * bd["question_mask"]
         batches.append(bd)
     to_gpu = lambda bd: {k: (v.cuda() if torch.is_tensor(v) else {kk: vv.cuda() for kk, vv in v.items()}) for k, v in bd.items()}

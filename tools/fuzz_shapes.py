@@ -32,6 +32,13 @@ for k in range(count):
     except Exception as e:          # noqa: BLE001
         bad += 1
         print("TRAIN FAIL ", tag, "::", str(e).splitlines()[0][:200] if str(e) else traceback.format_exc()[-300:], flush=True)
+    if os.environ.get("FUZZ_TRAINER", "1") != "0" and k % 3 == 0:          # (six oracle optimisation steps on the CPU: every third shape)
+        try:
+            tm.test_training_trajectory_matches_oracle_train_step(shapes, layers, ctx, batch)
+            print("TRAINER ok ", tag, flush=True)
+        except Exception as e:      # noqa: BLE001
+            bad += 1
+            print("TRAINER FAIL", tag, "::", str(e).splitlines()[0][:200] if str(e) else traceback.format_exc()[-300:], flush=True)
     if n_dec >= 2 and shapes[2] >= 1:
         mp = pytest.MonkeyPatch()
         try:
