@@ -601,7 +601,13 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     host_ms = []
+    # The host submits a replayed step in ~0.7 ms and would run up to 100 steps ahead of the GPU; a training loop never does (it reads a loss every few steps).
+    # At most `inflight` steps are kept queued: with an unbounded queue half of the 120-step runs showed ONE 30-37 ms step (host call and device step stalled
+    # together, never in 20-step runs: profiles/r5_bench_stalls.txt) -- a queue that deep is not what the metric is about.
+    inflight = int(os.environ.get("SAM_BENCH_INFLIGHT", "8"))
     for j in range(args.steps):
+        if inflight > 0 and j >= inflight:
+            marks[j + 1 - inflight].synchronize()
         h0 = time.perf_counter()
         loss = trainer.step(next_batch(args.warmup + j, batch))
         marks[j + 1].record()
