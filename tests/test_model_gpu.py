@@ -636,7 +636,7 @@ def test_rccl_path_one_rank_matches_plain_trainer(tmp_path, three_groups):
     run_child([sys.executable, "-c", _DIST_SCRIPT], env, "DIST_OK", "rccl_one_rank_%s" % ("three_groups" if three_groups else "two_groups"))
 
 
-def test_training_trajectory_matches_oracle_train_step(shapes=(20, 100, 50, 12), layers=("n", "s"), ctx=3, batch=3):
+def test_training_trajectory_matches_oracle_train_step(shapes=(20, 100, 50, 12), layers=("n", "s"), ctx=3, batch=3, check_descent=True):
     """SURVEY §8a a-18 end to end: six optimisation steps (forward, masked BCE, backward, clip 0.25, Adam, LambdaLR warm-up) of the HIP
     Trainer against the oracle's train_step (train.py:133-144 restated) from identical weights on identical batches, dropout off.
     (The arguments are for tools/fuzz_shapes.py, which calls this with random shapes.)"""
@@ -659,7 +659,7 @@ def test_training_trajectory_matches_oracle_train_step(shapes=(20, 100, 50, 12),
         l_ref.append(O.train_step(ref, clone_batch(bd), opt, sched).item())
         l_hip.append(tr.step(to_gpu(clone_batch(bd))).item())
     assert all(abs(a - b) <= 0.02 * abs(b) for a, b in zip(l_hip, l_ref)), (l_hip, l_ref)
-    assert l_ref[-1] < l_ref[0]
+    assert not check_descent or l_ref[-1] < l_ref[0]          # (a property of the scenario, not of the product: the fuzzer's random shapes switch it off)
     # where the optimiser took the parameters: direction and size of the total update, per tensor family
     sd = tr.state_dict()["model_state_dict"]
     cos, rel = [], []

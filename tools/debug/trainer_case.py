@@ -9,7 +9,7 @@ from tests import test_model_gpu as tm  # noqa: E402
 ctx, layers = int(sys.argv[1]), tuple(sys.argv[2])
 shapes, batch = tuple(int(x) for x in sys.argv[3:7]), int(sys.argv[7])
 try:
-    tm.test_training_trajectory_matches_oracle_train_step(shapes, layers, ctx, batch)
+    tm.test_training_trajectory_matches_oracle_train_step(shapes, layers, ctx, batch, False)
     print("ok")
 except Exception:      # noqa: BLE001
     traceback.print_exc()

@@ -34,7 +34,7 @@ for k in range(count):
         print("TRAIN FAIL ", tag, "::", str(e).splitlines()[0][:200] if str(e) else traceback.format_exc()[-300:], flush=True)
     if os.environ.get("FUZZ_TRAINER", "1") != "0" and k % 3 == 0:          # (six oracle optimisation steps on the CPU: every third shape)
         try:
-            tm.test_training_trajectory_matches_oracle_train_step(shapes, layers, ctx, batch)
+            tm.test_training_trajectory_matches_oracle_train_step(shapes, layers, ctx, batch, False)
             print("TRAINER ok ", tag, flush=True)
         except Exception as e:      # noqa: BLE001
             bad += 1
