@@ -625,12 +625,29 @@ def main():
         parallel.dist.all_reduce(t, op=parallel.dist.ReduceOp.MAX)
         dt = t.item()
     final_loss = float(loss.item())
+    # EVERY collective of this command is issued by EVERY rank: whatever enqueues one (the exposed-communication leg below runs four more data-parallel
+    # steps) happens here, before the ranks part ways.  Round 5 sent ranks != 0 into the closing barrier first and let rank 0 run those steps alone:
+    # mismatched collectives on one communicator, i.e. a hang at N > 1 and no JSON line.
+    comm_leg = {}
+    if trainer.reducer is not None:
+        comm_leg["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)        # (eager data-parallel steps: measured on the timed steps themselves)
+        if trainer._graph is not None or os.environ.get("SAM_BENCH_EAGER_COMM_LEG") == "1":
+            # the exchange is inside the captured step, where no timing event can sit: the exposed part is measured on a few eager steps of the same trainer
+            was_graph = trainer.use_graph
+            trainer.measure_comm, trainer.use_graph = True, False
+            for _ in range(4):
+                trainer.step(clone_batch(batch))
+            comm_leg["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
+            comm_leg["exposed_comm_source"] = "4 eager steps after the timed region, run by every rank (%s)" % (
+                "the timed steps replay a graph that contains the exchange" if trainer._graph is not None else "forced by SAM_BENCH_EAGER_COMM_LEG=1; the timed steps were eager too")
+            trainer.use_graph = was_graph
+        trainer.measure_comm = False
+        torch.cuda.synchronize()
     if rank != 0:
-        parallel.dist.barrier()
+        parallel.dist.barrier()               # pairs with rank 0's closing barrier (after it has printed the line): nothing else is issued in between
         parallel.dist.destroy_process_group()
         return
     gb = args.batch * world
-    trainer.measure_comm = False
     res = {
         "metric": "training samples/sec, SA-M4C c=%d synthetic batch" % args.context, "value": round(gb * args.steps / dt, 2), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
@@ -666,20 +683,13 @@ def main():
     if trainer is not None and trainer.reducer is not None:
         # GPU time between the end of the backward pass and the end of the gradient exchange, averaged over the timed steps: what the
         # all-reduce costs beyond what the backward hides
-        res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
+        res.update(comm_leg)
         res["overlap"] = bool(trainer.reducer.overlap)
         res["grad_payload"] = trainer.reducer.payload
         # "rccl-direct": ncclAllReduce / ncclAllGather enqueued by the reducer itself on its stream over the group's communicator (sam_textvqa_amd/rccl.py);
         # "process-group": torch.distributed calls (gloo, or SAM_RCCL_DIRECT=0)
         res["dp_transport"] = "rccl-direct" if trainer.reducer.comm is not None else "process-group"
     res["step_mode"] = "hipGraph replay" if (trainer.use_graph and trainer._graph is not None) else "eager launches"
-    if trainer.reducer is not None and trainer._graph is not None:
-        # the exchange is inside the captured step, where no timing event can sit: the exposed part is measured on a few eager steps of the same trainer
-        trainer.measure_comm, trainer.use_graph = True, False
-        for _ in range(4):
-            trainer.step(clone_batch(batch))
-        res["exposed_comm_ms"] = round(trainer.exposed_comm_ms(), 3)
-        res["exposed_comm_source"] = "4 eager steps after the timed region (the timed steps replay a graph that contains the exchange)"
     if world == 1 and not args.no_secondary and os.environ.get("SAM_FORCE_DIST") != "1":
         # SURVEY 8(d)'s other rows, each a short run OUTSIDE the timed region (numbers of this process, same code path as the headline)
         sec = []

@@ -460,7 +460,7 @@ class DeferredWgrads:
     Their data-parallel regions are reported done after that launch, in backward order.  Without a gradient reducer the MMT's last layer group waits for them
     (`held`) and the two go out as one launch of 20 problems of mixed depth (flush)."""
     jobs, layers, acc = [], [], None
-    late_stream, late = None, []
+    late = []                   # [(jobs, stream)]: operand sets a launch on `stream` is (or may still be) reading; join() / clear() wait for each stream named here
     side_stream = None
     held = []                   # [(jobs, layers, acc, event)]: the MMT's last group, waiting for TextBert's problems (flush)
     extra_events = []           # one event per extra, recorded where its operands were produced
@@ -533,8 +533,7 @@ class DeferredWgrads:
                     ops.wgrad_grouped(hjobs + jobs, accumulate=acc)
                     for layer in hlayers + layers:
                         region_done(getattr(layer, "_sam_region_id", None))
-                cls.late.append(hjobs + jobs)
-                cls.late_stream = cls.side_stream
+                cls.late.append((hjobs + jobs, cls.side_stream))
                 return
             torch.cuda.current_stream().wait_event(ev)
             if jobs and hacc == acc and len(hjobs) + len(jobs) <= 20:
@@ -543,8 +542,7 @@ class DeferredWgrads:
                 ops.wgrad_grouped(hjobs, accumulate=hacc)
                 for layer in hlayers:
                     region_done(getattr(layer, "_sam_region_id", None))
-            cls.late.append(hjobs)                  # operands of the held group were allocated on another stream: alive until join()
-            cls.late_stream = torch.cuda.current_stream()
+            cls.late.append((hjobs, torch.cuda.current_stream()))      # operands of the held group were allocated on another stream: alive until join()
             if not jobs:
                 return
         elif armed:
@@ -558,19 +556,16 @@ class DeferredWgrads:
             cur = torch.cuda.current_stream()
             if cls.side_stream is None:
                 cls.side_stream = torch.cuda.Stream()
-            cls.late_stream = cls.side_stream
-            cls.late_stream.wait_stream(cur)
-            with torch.cuda.stream(cls.late_stream):
+            cls.side_stream.wait_stream(cur)
+            with torch.cuda.stream(cls.side_stream):
                 ops.wgrad_grouped(jobs, accumulate=acc)
                 for layer in layers:
                     region_done(getattr(layer, "_sam_region_id", None))
-            cls.late.append(jobs)                 # operands were allocated on the issuing stream: alive until join()
+            cls.late.append((jobs, cls.side_stream))       # operands were allocated on the issuing stream: alive until join()
             return
         if cls.extras and len(jobs) + len(cls.extras) <= 20:
             cls._wait_extras()
-            cls.late.append(cls.extras)     # (allocated on another stream: alive until join())
-            if cls.late_stream is None:
-                cls.late_stream = torch.cuda.current_stream()
+            cls.late.append((cls.extras, torch.cuda.current_stream()))     # (allocated on another stream: alive until join(); the launch below reads them HERE)
             jobs, cls.extras = list(jobs) + cls.extras, []
         if jobs:
             ops.wgrad_grouped(jobs, accumulate=bool(acc))
@@ -584,9 +579,7 @@ class DeferredWgrads:
             cls._wait_extras()
             jobs, cls.extras = cls.extras, []
             ops.wgrad_grouped(jobs, accumulate=True)
-            cls.late.append(jobs)
-            if cls.late_stream is None:
-                cls.late_stream = torch.cuda.current_stream()
+            cls.late.append((jobs, torch.cuda.current_stream()))
 
     @classmethod
     def _wait_extras(cls):
@@ -597,18 +590,31 @@ class DeferredWgrads:
 
     @classmethod
     def join(cls):
-        """the current stream waits for a weight-gradient launch that went to the side (flush(late=True))"""
-        if cls.late:
-            torch.cuda.current_stream().wait_stream(cls.late_stream)
-            cls.late = []
+        """the current stream waits for every weight-gradient launch that went to the side (flush(late=True)) or took operands of another stream: each entry
+        names the stream ITS launch was issued on (round 5 kept one class-wide `late_stream` that was never reset: from the second step on it could name last
+        step's stream while the extras had gone out on another)"""
+        cur = torch.cuda.current_stream()
+        for st in cls._late_streams():
+            if st != cur:
+                cur.wait_stream(st)
+        cls.late = []
+
+    @classmethod
+    def _late_streams(cls):
+        out = []
+        for _, st in cls.late:
+            if st is not None and all(st != o for o in out):
+                out.append(st)
+        return out
 
     @classmethod
     def clear(cls):
         cls.jobs, cls.layers, cls.acc = [], [], None
         cls.held, cls.extras, cls.extra_events = [], [], []
-        if cls.late:                 # a launch may still be reading its operands on the late stream: the issuing stream waits before they are dropped
+        for st in cls._late_streams():      # a launch may still be reading its operands on its stream: the issuing stream waits before they are dropped
             try:
-                torch.cuda.current_stream().wait_stream(cls.late_stream)
+                if st != torch.cuda.current_stream():
+                    torch.cuda.current_stream().wait_stream(st)
             except RuntimeError:
                 pass
         cls.late = []

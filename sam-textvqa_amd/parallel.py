@@ -93,20 +93,30 @@ class GradReducer:
 
     def _resolve_comm(self):
         """the group's ncclComm_t when the group is an RCCL group: the collectives are then enqueued directly on the reducer's stream (rccl.py) -- no
-        ProcessGroupNCCL Work objects, no watchdog polling of the step's events.  None: gloo (tests), SAM_RCCL_DIRECT=0, a 1-rank job without a group."""
+        ProcessGroupNCCL Work objects, no watchdog polling of the step's events.  None: gloo (tests), SAM_RCCL_DIRECT=0, a 1-rank job without a group.
+        The choice is AGREED over the group: a rank whose lookup failed (rccl.communicator swallows local errors) would otherwise call
+        dist.all_to_all_single while its peers call ncclAllToAll on the same communicator -- a hang.  Every rank runs the same collectives here, in the
+        same order, whatever its own lookup returned: one warm-up all-reduce (the communicator is built lazily by the group's first collective; every
+        rank constructs its reducer at the same point) and one MIN all-reduce of the "have it" flag."""
         if not (self.grad.is_cuda and dist.is_initialized() and (self.world_size > 1 or self.force)):
             return None
-        comm = rccl.communicator(self.group)
         try:
-            is_rccl = dist.get_backend(self.group) == "nccl" and os.environ.get("SAM_RCCL_DIRECT", "1") != "0"
+            is_rccl = dist.get_backend(self.group) == "nccl"
         except Exception:
             is_rccl = False
-        if comm is None and is_rccl:
-            # the communicator is built lazily by the group's first collective: make it happen (every rank constructs its reducer at the same point)
-            t = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
-            dist.all_reduce(t, group=self.group)
-            torch.cuda.synchronize()
-            comm = rccl.communicator(self.group)
+        if not is_rccl:
+            return None                                    # (the backend is a property of the group: the same answer on every rank)
+        t = torch.zeros(1, dtype=torch.float32, device=self.grad.device)
+        dist.all_reduce(t, group=self.group)               # unconditional: builds the communicator where the group has not used it yet
+        torch.cuda.synchronize()
+        comm = rccl.communicator(self.group)               # (None under SAM_RCCL_DIRECT=0)
+        have = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=self.grad.device)
+        dist.all_reduce(have, op=dist.ReduceOp.MIN, group=self.group)
+        if not int(have.item()):
+            if comm is not None:
+                import logging
+                logging.getLogger(__name__).warning("another rank has no direct RCCL communicator: the whole group stays on torch.distributed calls")
+            return None
         return comm
 
     def _build_buckets(self, cut):
@@ -262,7 +272,9 @@ class GradReducer:
     def broadcast(self, t, src=0):
         """rank `src`'s t to every rank, complete on return (start-up: masters and optimizer state)"""
         if self.comm is not None:
-            rccl.broadcast(self.comm, t.view(-1) if t.is_contiguous() else t, src)
+            # `src` is a GLOBAL rank (torch.distributed's convention); ncclBroadcast wants the rank inside the communicator, i.e. inside the group
+            root = dist.get_group_rank(self.group, src) if self.group is not None else src
+            rccl.broadcast(self.comm, t.view(-1) if t.is_contiguous() else t, root)
             torch.cuda.synchronize()
         else:
             dist.broadcast(t, src=src, group=self.group)
@@ -341,6 +353,13 @@ def _scatter_rows(grad_table, ids, rows, padding_idx):
     (index, row) list, add up bit-identical gradients and the replicas stay in lock-step (atomics would sum in an arbitrary order per rank).
     There is no CPU implementation in the package: the gloo unit test of GradReducer injects its own `scatter_fn`."""
     from . import ops
+    # sam_embedding_bwd takes its fixed-order (first-occurrence owner) kernel only for 16-byte aligned tables whose row stride is a multiple of 4 floats,
+    # and not under SAM_EMBED_BWD_ATOMIC=1; otherwise it falls back to fp32 atomics, whose order differs from rank to rank: replicas would drift with no
+    # diagnostic.  Under the data-parallel exchange that is an error, not a fallback.
+    if os.environ.get("SAM_EMBED_BWD_ATOMIC") == "1" or grad_table.stride(0) % 4 or grad_table.data_ptr() % 16:
+        raise RuntimeError("data-parallel row-sparse scatter needs the deterministic sam_embedding_bwd kernel: table row stride %d (must be a multiple of 4), "
+                           "address %% 16 = %d (must be 0), SAM_EMBED_BWD_ATOMIC=%s (must be unset)"
+                           % (grad_table.stride(0), grad_table.data_ptr() % 16, os.environ.get("SAM_EMBED_BWD_ATOMIC")))
     ops.embedding_bwd((rows if rows.dtype == torch.bfloat16 else rows.to(torch.bfloat16)).contiguous(), ids.contiguous(), grad_table, padding_idx)
 
 

@@ -33,10 +33,19 @@ def _loaded_rccl_path():
     return None
 
 
+def library_path():
+    """the librccl.so this process would bind: the one already mapped (the one that built the group's communicator), else torch's own; None when neither exists"""
+    path = _loaded_rccl_path() or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+    return path if os.path.exists(path) else None
+
+
 def lib():
     global _lib
     if _lib is None:
-        path = _loaded_rccl_path() or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = library_path()
+        if path is None:
+            raise RuntimeError("sam_textvqa_amd.rccl: no librccl.so is mapped into this process and none sits next to torch (%s): the direct RCCL transport "
+                               "needs the ROCm build of torch; gloo / SAM_RCCL_DIRECT=0 use torch.distributed calls instead" % os.path.join(os.path.dirname(torch.__file__), "lib"))
         l = ctypes.CDLL(path)
         vp, sz, i = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int
         l.ncclAllReduce.argtypes, l.ncclAllReduce.restype = [vp, vp, sz, i, i, vp, vp], i

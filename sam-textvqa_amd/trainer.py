@@ -277,6 +277,17 @@ class Trainer:
         red = self.reducer
         if os.environ.get("SAM_DP_GRAPH", "1") == "0" or red.check or not parallel.dist.is_initialized():
             return False
+        # ... and ONLY when the reducer enqueues them itself (rccl.py, `red.comm`): a step captured with torch.distributed calls inside holds
+        # ProcessGroupNCCL Work objects whose events the group's watchdog polls from another thread -- the capture-invalidating query that ends in
+        # std::terminate (rccl.py's header; round 4 lost 191 tests to it).  Without the direct transport (SAM_RCCL_DIRECT=0, a torch without
+        # _comm_ptr, ranks that did not all get a communicator: GradReducer._resolve_comm agrees on it) the data-parallel step runs eagerly.
+        if red.comm is None:
+            if not getattr(self, "_warned_no_direct", False) and self.use_graph:
+                self._warned_no_direct = True
+                import logging
+                logging.getLogger(__name__).warning("data-parallel step NOT captured: the reducer has no direct RCCL communicator (SAM_RCCL_DIRECT=0 or "
+                                                    "_comm_ptr unavailable); collectives go through torch.distributed, launches stay eager")
+            return False
         try:
             return parallel.dist.get_backend(red.group) == "nccl"
         except Exception:

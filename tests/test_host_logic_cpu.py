@@ -1,9 +1,13 @@
 """CPU: host-side logic of the product package that needs no kernels — config objects, module surface / state_dict keys,
 LR schedule, synthetic batch schema, reducer bucket planning."""
+import os
+
 import torch
 
 from oracle import sa_m4c_oracle as O
 from tests import oracle_cases as OC
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_config_from_dict_copies_every_key():
@@ -168,3 +172,37 @@ def test_shipped_reference_configs_build_the_model_unchanged():
             bd = {"spatial_adj_matrices": {"3": None, "1": None}}
             with pytest.raises(KeyError, match="mix_list"):
                 enc._adjacency_for(bd, enc.mix_list[-1])
+
+
+def test_bench_issues_no_collective_after_the_ranks_part_ways():
+    """bench.py sent ranks != 0 into the closing barrier and let rank 0 run four more data-parallel steps alone -- mismatched collectives,
+    no JSON line at N > 1.  Everything that enqueues a collective (a trainer step under a reducer, an all-reduce, the exposed-communication read-out) must
+    sit BEFORE the `if rank != 0:` return; behind it rank 0 may only compute locally, print, and meet the others in ONE closing barrier."""
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    main = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "main")
+    split = None
+    for i, node in enumerate(main.body):
+        if isinstance(node, ast.If) and isinstance(node.test, ast.Compare) and getattr(node.test.left, "id", None) == "rank" \
+                and isinstance(node.test.ops[0], ast.NotEq) and any(isinstance(x, ast.Return) for x in node.body):
+            split = i
+    assert split is not None, "bench.py no longer has the rank != 0 early return this test anchors on"
+    tail = ast.Module(body=main.body[split + 1:], type_ignores=[])
+    barriers = 0
+    for node in ast.walk(tail):
+        if isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute):
+            name = node.func.attr
+            owner = ast.unparse(node.func.value)
+            if name == "barrier":
+                barriers += 1
+                continue
+            assert not (name == "step" and owner == "trainer"), "trainer.step() behind the rank split (line %d)" % node.lineno
+            assert name not in ("all_reduce", "all_gather", "all_gather_into_tensor", "broadcast", "reduce_scalar", "all_to_all_single"), \
+                "collective %s behind the rank split (line %d)" % (name, node.lineno)
+            assert not (name == "exposed_comm_ms"), "exposed_comm_ms() behind the rank split (line %d): it closes a leg every rank must run" % node.lineno
+    assert barriers == 1
+    # the rank != 0 branch itself: one barrier (the partner of rank 0's closing one), destroy, return
+    node = main.body[split]
+    calls = [n.func.attr for n in ast.walk(node) if isinstance(n, ast.Call) and isinstance(n.func, ast.Attribute)]
+    assert calls == ["barrier", "destroy_process_group"], calls

@@ -163,6 +163,35 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
     assert out.get("dp_transport") == "rccl-direct"
 
 
+def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
+    """`bench.py --gpus N` with N > 1 must FINISH.  The driver's exact command at --nproc-per-node 2, both ranks on this box's one GPU
+    (gloo's CUDA-tensor collectives stand in for RCCL, which refuses two ranks on one device; the step is therefore eager -- SAM_BENCH_EAGER_COMM_LEG=1 forces
+    the exposed-communication leg that a captured step takes, the leg round 5 ran on rank 0 only).  The JSON line must appear, from rank 0, with n_gpus = 2,
+    two ranks seen by the reducer's group, the global batch of both -- inside 300 s (a mismatched collective hangs for ever)."""
+    import json
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1", SAM_BENCH_EAGER_COMM_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAM_FORCE_DIST", "SAM_REDUCER_CHECK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
+    from tests.util import run_child
+    r = run_child(cmd, env, None, "bench_dist_run_two_ranks", timeout=300)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                      # rank 0 prints, rank 1 does not
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert key in out, key
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 2 and out["scaling"] == "weak" and out["value"] > 0
+    assert out["rccl_ranks_seen"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
+    assert out["exposed_comm_ms"] >= 0.0 and "every rank" in out["exposed_comm_source"]
+    assert out["dp_transport"] == "process-group" and out["step_mode"] == "eager launches"
+    assert abs(out["value"] - 128 * 3 / (out["ms_per_step"] * 3e-3)) <= 0.02 * out["value"]
+
+
 _GRAPH_DP_SCRIPT = r"""
 import os, sys, torch
 sys.path.insert(0, os.environ["SAM_REPO"])
