@@ -677,6 +677,9 @@ def main():
         res["kernels"] = table
     if world == 1 and args.pmc and "roofline" in res:
         apply_live_pmc(res, live_pmc(args))
+    res["cu_reserved"] = int(getattr(trainer, "cu_reserved", 0))     # CUs the persistent grids leave free (for RCCL's channel kernels at N > 1; 0 at N = 1 unless SAM_CU_RESERVE)
+    if world > 1:
+        res["nccl_max_nchannels"] = os.environ.get("NCCL_MAX_NCHANNELS")
     if ranks_seen is not None:
         res["rccl_ranks_seen"] = ranks_seen          # all-reduce of a one per rank over the reducer's group, just before the timed region
         res["dist_backend"] = parallel.dist.get_backend()

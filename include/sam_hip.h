@@ -30,6 +30,14 @@ int sam_abi_version(void);
 const char* sam_build_digest(void);
 const char* sam_last_error(void);
 int sam_device_info(int* cu_count, int* lds_per_cu_bytes, char* arch, int arch_len);
+/* CUs withheld from every persistent grid of the training step (GEMMs, grouped weight gradient, one-pass attention backward): n is rounded down to a multiple of
+ * 8 (each XCD gives up the same number), 0 <= n <= 128; default SAM_CU_RESERVE from the environment, else 0.  Replaces nothing in the reference -- its
+ * nn.DataParallel (train.py:111-112) has no kernel whose grid is sized from the device; here every hot kernel is, and RCCL's channel kernels need CUs beside them
+ * (DESIGN.md section 6).  Launches already captured into a hipGraph keep the grid they were captured with. */
+int sam_set_cu_reserve(int n);
+int sam_get_cu_reserve(void);
+/* measurement aid (tools/bench_cu_reserve.py): `blocks` workgroups that each hold one CU's LDS for `microseconds` -- a stand-in for a collective's channel kernel */
+int sam_debug_cu_hog(int blocks, double microseconds, void* stream);
 
 /* ---- allow-bit masks (built once per batch; bit k of word w of row (b,h,q) <=> key 32w+k visible) ---- */
 /* words per mask row for sequence length N (= padded keys / 32); -1 if N exceeds the fused kernel (384) */
@@ -411,6 +419,11 @@ typedef struct sam_copy_desc {
 } sam_copy_desc;
 int sam_copy_blocks(const sam_copy_desc* descs, int count, void* stream);
 int sam_ge_u8(const int64_t* x, int64_t n, int64_t threshold, uint8_t* out, void* stream);
+/* element-wise row kernels of the stand-alone sub-modules (bf16 rows [rows, cols], fp32 arithmetic, one rounding; cols and strides multiples of 4):
+ *   mode 0: out = a * b      -- BertIntermediate's backward, dy * gelu'(pre) with the derivative the forward GEMM stored (sa_m4c.py:678, 985-991)
+ *   mode 1: out = a + vec    -- SpatialBertSelfAttention's `use_bias` head biases, context_layer + biases(0) (sa_m4c.py:439-443, 600-603); vec fp32 [cols]
+ *   mode 2: out = a * vec    -- head_mask as one factor per head, broadcast over the head's 64 context columns (sa_m4c.py:591-592: probs * head_mask before P V) */
+int sam_rowvec_bf16(int mode, const void* a, int64_t lda, const void* b, int64_t ldb, const float* vec, void* out, int64_t ldo, int64_t rows, int cols, void* stream);
 
 /* ---- dropout RNG state in device memory (hipGraph capture) ----
  * Every dropout site takes (seed, offset) BY VALUE (counter-based: the backward regenerates the forward's mask from the same pair).  Launches

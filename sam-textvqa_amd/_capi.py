@@ -90,8 +90,12 @@ SIGNATURES = {
     "sam_copy_blocks": [C.c_void_p, _i, _vp],
     "sam_ge_u8": [_vp, _i64, _i64, _vp, _vp],
     "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
+    "sam_rowvec_bf16": [_i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i, _vp],
+    "sam_set_cu_reserve": [_i],
+    "sam_get_cu_reserve": [],
+    "sam_debug_cu_hog": [_i, C.c_double, _vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_attn_bwd_fused_max_n", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_get_cu_reserve", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_attn_bwd_fused_max_n", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
 RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
 
 _lib = None

@@ -729,6 +729,73 @@ class EncoderLayerFn(Function):
         return dx, None, None, None, None, None, None
 
 
+def _rows_bf16(t):
+    x2 = t.reshape(-1, t.shape[-1])
+    if x2.dtype != BF16 or x2.stride(1) != 1 or x2.stride(0) % 8 or x2.data_ptr() % 16:
+        x2 = x2.to(BF16).contiguous()
+    return x2
+
+
+class DenseDropoutResLnFn(Function):
+    """BertSelfOutput / BertOutput called as stand-alone modules (sam/sa_m4c.py:653, 680): LayerNorm(dropout(x W^T + b) + residual) through the SAME kernels the
+    fused encoder layer uses -- GEMM with the bias + dropout + residual epilogue, sam_layernorm_fwd; backward: sam_layernorm_bwd (which regenerates the
+    dropout mask and emits the masked gradient for the dense + its bias gradient), weight-gradient GEMM, dgrad GEMM.  No torch arithmetic."""
+
+    @staticmethod
+    def forward(ctx, x, residual, mod, p_drop):
+        dense, ln = mod.dense, mod.LayerNorm
+        n, k = dense.weight.shape
+        if n % 8 or k % 8:
+            raise capi.SamHipError("%s: hidden sizes must be multiples of 8 (got %d -> %d)" % (type(mod).__name__, k, n))
+        x2, r2 = _rows_bf16(x), _rows_bf16(residual)
+        seed = dropout_clock.next()
+        z, y, mean, rstd = ops.gemm_ln(x2, _w(dense.weight), ln.weight, ln.bias, ln.variance_epsilon, epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=dense.bias,
+                                       residual=r2, p_drop=p_drop, seed=seed[0], offset=seed[1])
+        ctx.save_for_backward(x2, z, mean, rstd)
+        ctx.mod, ctx.p_drop, ctx.seed, ctx.shapes = mod, p_drop, seed, (x.shape, x.dtype, residual.shape, residual.dtype)
+        return y.view(*residual.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, z, mean, rstd = ctx.saved_tensors
+        dense, ln = ctx.mod.dense, ctx.mod.LayerNorm
+        xs, xd, rs, rd = ctx.shapes
+        dy2 = _rows_bf16(dy)
+        dz, dyd = ops.layernorm_bwd(dy2, z, mean, rstd, ln.weight, ln.weight.grad, ln.bias.grad, dbias=dense.bias.grad, want_dropped=True, p_drop=ctx.p_drop,
+                                    seed=ctx.seed[0], offset=ctx.seed[1], accumulate=True)
+        ops.gemm(dyd, x2, a_kcontig=False, b_kcontig=False, out=dense.weight.grad, accumulate=True, split_k=-1)          # dW += dyd^T x
+        dx = ops.gemm(dyd, _w(dense.weight), b_kcontig=False).view(xs).to(xd) if ctx.needs_input_grad[0] else None       # dx = dyd W
+        return dx, (dz.view(rs).to(rd) if ctx.needs_input_grad[1] else None), None, None
+
+
+class DenseGeluFn(Function):
+    """BertIntermediate as a stand-alone module (sa_m4c.py:678, 985-991): erf-GELU(x W^T + b) in the GEMM's epilogue, which also stores gelu'(pre) when a
+    backward will follow; backward: dpre = dy * gelu' (sam_rowvec_bf16), weight gradient with the bias gradient fused, dgrad."""
+
+    @staticmethod
+    def forward(ctx, x, mod, want_grad):
+        dense = mod.dense
+        n, k = dense.weight.shape
+        if n % 8 or k % 8:
+            raise capi.SamHipError("BertIntermediate: sizes must be multiples of 8 (got %d -> %d)" % (k, n))
+        x2 = _rows_bf16(x)
+        dact = torch.empty((x2.shape[0], n), dtype=BF16, device=x2.device) if want_grad else None
+        h = ops.gemm(x2, _w(dense.weight), epilogue=capi.EPI_BIAS_GELU_GRAD, bias=dense.bias, aux_out=dact)
+        if want_grad:
+            ctx.save_for_backward(x2, dact)
+        ctx.mod, ctx.shape, ctx.dtype = mod, x.shape, x.dtype
+        return h.view(*x.shape[:-1], n)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, dact = ctx.saved_tensors
+        dense = ctx.mod.dense
+        dpre = ops.rowvec("mul", _rows_bf16(dy), dact)
+        ops.gemm(dpre, x2, a_kcontig=False, b_kcontig=False, out=dense.weight.grad, accumulate=True, split_k=-1, bias_grad=dense.bias.grad)
+        dx = ops.gemm(dpre, _w(dense.weight), b_kcontig=False).view(ctx.shape).to(ctx.dtype) if ctx.needs_input_grad[0] else None
+        return dx, None, None
+
+
 def coarse_ops_active():
     """the C++ per-layer ops are used unless switched off (SAM_COARSE_OPS=0) or bench.py's per-kernel event profiler is recording"""
     return torchops.enabled() and capi.profiler is None

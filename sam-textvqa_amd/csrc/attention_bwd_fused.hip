@@ -16,6 +16,7 @@
 // ~10 VALU per score + ~3 for the fp16 staging.  LDS at 12 key tiles (N <= 192): 3 x 24 KB tiles + 72 KB dS + 11 KB = 155 KB, one
 // block of 12 waves per CU.  Longer sequences keep the two-kernel form (attention.hip).
 #include "attn_common.h"
+extern "C" int sam_get_cu_reserve(void);
 
 using namespace attn;
 
@@ -605,16 +606,19 @@ template <int NKT>
 int launch_fused(const AttnArgs& a, hipStream_t st) {
   typedef FusedLds<NKT> L;
   static bool once = false;
-  static int n_cu = 0;
+  static int n_phys = 0;
   if (!once) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT, true>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NKT, false>), hipFuncAttributeMaxDynamicSharedMemorySize, L::BYTES);
     int dev = 0;
     hipGetDevice(&dev);
-    hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
-    if (n_cu <= 0) n_cu = 256;
+    hipDeviceGetAttribute(&n_phys, hipDeviceAttributeMultiprocessorCount, dev);
+    if (n_phys <= 0) n_phys = 256;
     once = true;
   }
+  // (CUs withheld from persistent grids while collectives run beside the backward pass: sam_set_cu_reserve, gemm_common.h)
+  const int reserve = sam_get_cu_reserve();
+  const int n_cu = (reserve > 0 && n_phys - reserve >= 8) ? n_phys - reserve : n_phys;
   // blocks per CU the LDS footprint admits; with one (12 key tiles) the grid is one block per CU and every block walks several heads,
   // prefetching the next one's operands while it computes (the loop degenerates to a single trip when there are at least as many slots as heads)
   const int per_cu = (160 * 1024) / L::BYTES > 0 ? (160 * 1024) / L::BYTES : 1;

@@ -280,10 +280,19 @@ int launch12(GemmArgs a, int n_cu, hipStream_t st) {
 
 template <bool BKC, int EPI>
 int pick12(const GemmArgs& a, int tile, hipStream_t st) {
-  const int n_cu = device_cu_count();
+  const int n_cu = grid_cu_count();
   // 192 x 256 for the wide outputs (N a multiple of 256 with >= 2.5 rounds of tiles), 192 x 192 (three stages) otherwise; `tile`: 12192 / 12448 force one
   const int t256 = ((a.M + 191) / 192) * ((a.N + 255) / 256);
-  const bool wide = tile == 12448 || (tile != 12192 && a.N % 256 == 0 && t256 >= 2 * n_cu + n_cu / 2);
+  bool wide = tile == 12448 || (tile != 12192 && a.N % 256 == 0 && t256 >= 2 * n_cu + n_cu / 2);
+  if (tile == 0 && a.N % 256 == 0 && n_cu != device_cu_count()) {
+    // CUs withheld (sam_set_cu_reserve): the rule above was tuned on the full chip, where 11648 x 768 is 244 tiles of 192 x 192 on 256 CUs -- ONE round; on
+    // 240 or 224 CUs it is two, the second nearly empty.  Makespan of both shapes, same model as gemm8.hip's picker (rounds x (k-tiles x tk + streams x es))
+    const int64_t t192 = (int64_t)((a.M + 191) / 192) * ((a.N + 191) / 192);
+    const float streams = 1.f + ((EPI == SAM_EPI_BIAS_GELU_GRAD) ? 1.f : 0.f) + (((EPI == SAM_EPI_BIAS_DROPOUT_RES && a.residual) || EPI == SAM_EPI_MUL_AUX) ? 1.f : 0.f);
+    const float kt = (float)(a.K / BK);
+    const float c192 = (float)((t192 + n_cu - 1) / n_cu) * (kt * 1.14f + streams * 4.7f), c256 = (float)((t256 + n_cu - 1) / n_cu) * (kt * 1.27f + streams * 4.9f);
+    wide = c256 < c192;
+  }
   if (wide) return launch12<192, 256, true, BKC, EPI, bf16_t, 2>(a, n_cu, st);
   static int ph = -1;
   if (ph < 0) { const char* v = getenv("SAM_GEMM12_PHASES"); ph = v ? atoi(v) : 1; }          // (2: the two-phase schedule, for an A/B)
@@ -300,7 +309,7 @@ int samgemm::gemm12_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, i
   if (lay == 0 && c_is_f32 && e == SAM_EPI_NONE && tile == 12448 && a.K % BK == 0 && a.bias_grad == nullptr && a.M % 8 == 0) {
     // (experiment: the weight-gradient layout -- both operands k-strided, fp32 accumulate -- on the loader-wave core, one problem; profiles/r5_gemm_experiments.txt)
     if ((int64_t)a.K * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)a.K * a.ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;
-    return launch12<192, 256, false, false, SAM_EPI_NONE, float, 2>(a, device_cu_count(), st);
+    return launch12<192, 256, false, false, SAM_EPI_NONE, float, 2>(a, grid_cu_count(), st);
   }
   if (a.K % BK != 0 || a.split_k > 1 || a.bias_grad != nullptr || c_is_f32 || !(lay & 2)) return SAM_ERR_UNSUPPORTED;
   const int64_t a_rows = a.M, b_rows = (lay & 1) ? a.N : a.K;
@@ -309,7 +318,7 @@ int samgemm::gemm12_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, i
   if (tile == 0 && a.N % 256 == 0) {
     // a problem that 256 x 256 tiles cover in whole rounds stays with the 8-wave kernel: per flop its tile reads a third less from LDS than a 192-row tile, which
     // is worth more than the loader waves (QKV forward, N = 2304: 414 tiles = 2 rounds at 81 %: 48.9 us there, 55.0 us here on 732 tiles of 192 x 192)
-    const int n_cu = device_cu_count();
+    const int n_cu = grid_cu_count();
     const int64_t t256 = (int64_t)((a.M + 255) / 256) * (a.N / 256), rounds = (t256 + n_cu - 1) / n_cu;
     if (2 * t256 >= 3 * (int64_t)n_cu && 5 * t256 >= 4 * rounds * n_cu) return SAM_ERR_UNSUPPORTED;
   }

@@ -497,13 +497,13 @@ static bool plan12(const sam_gemm_desc* descs, int count, int n_cu, int* order, 
 
 int64_t gemm12w_ws_bytes(const sam_gemm_desc* descs, int count) {
   int order[MAXP], n_deep, n_total, rounds1, R, S, ktd, s_ws;
-  if (!plan12(descs, count, device_cu_count(), order, n_deep, n_total, rounds1, R, S, ktd, nullptr, s_ws) || R == 0) return 0;
+  if (!plan12(descs, count, grid_cu_count(), order, n_deep, n_total, rounds1, R, S, ktd, nullptr, s_ws) || R == 0) return 0;
   return ws12_bytes(R, s_ws);
 }
 
 // returns SAM_ERR_UNSUPPORTED when the set is not one for this kernel (the caller goes on to gemm8w_grouped / the 4-wave kernel)
 int gemm12w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
-  const int n_cu = device_cu_count();
+  const int n_cu = grid_cu_count();
   int order[MAXP];
   WArgs w = {};
   int s_ws = 0;

@@ -531,7 +531,7 @@ constexpr TileCfg kCfg[4] = {{256, 256, 1.43f, 6.0f, 6.0f}, {192, 192, 1.14f, 4.
 
 template <bool AKC, bool BKC, int EPI, typename OutT>
 int pick8(const GemmArgs& a, int tile, hipStream_t st) {
-  const int n_cu = device_cu_count();
+  const int n_cu = grid_cu_count();
   int best = -1; float best_score = 0.f;
   for (int c = 0; c < 4; ++c) {
     // 1192 / 1256 / 1448 / 1128: force 192x192 / 256x256 / 192x256 / 128x128; 3192: 192x192 with the deferred epilogue (measured slower)
@@ -577,7 +577,7 @@ int samgemm::gemm8_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, in
     // FFN2 dgrad, 1280 x 3072 x 768: 240 tiles, two blocks per CU; cold operands 15.4 / 14.1 us against 18.2 / 17.6 for the 64 x 64 four-wave tiles.  At MMT
     // size the configuration loses to the larger tiles on every shape -- 56 / 91 / 91 us for QKV / FFN1 / FFN2 against 49 / 82 / 69: twice the LDS traffic per flop)
     const int64_t t128 = (int64_t)((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (a.K >= 256 && a.K <= 1024 && t128 >= 200 && t128 <= 2 * device_cu_count()) tile = 1128;
+    if (a.K >= 256 && a.K <= 1024 && t128 >= 200 && t128 <= 2 * grid_cu_count()) tile = 1128;
     else return SAM_ERR_UNSUPPORTED;
   }
   if (lay == 3) {

@@ -308,7 +308,7 @@ int gemm8w_grouped(const sam_gemm_desc* descs, int count, hipStream_t st) {
     min_kt = d->K / BK < min_kt ? d->K / BK : min_kt;
   }
   w.tile_start[count] = tiles;
-  const int n_cu = device_cu_count();
+  const int n_cu = grid_cu_count();
   // the pair exchange spins on the partner, so both blocks of a tile must become resident: one launch round (tiles * 2 <= CUs, one block per
   // CU).  Partners have adjacent item ids (block ids b, b + 8), and workgroups are dispatched in id order: should other work hold some CUs,
   // the resident set is still a prefix of the ids, every pair inside it completes and frees its CUs -- the wait cannot deadlock.

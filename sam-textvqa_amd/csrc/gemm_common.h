@@ -307,6 +307,17 @@ inline int device_cu_count() {
   return cache[dev];
 }
 
+// CUs the persistent grids may fill: the device's count minus the reserve (sam_set_cu_reserve, runtime.cpp).  Every hot kernel of the training step is
+// persistent with one block per CU by LDS / registers: a kernel of another stream that holds k CUs for the length of the backward pass -- RCCL's channel
+// blocks under data-parallel training -- leaves k blocks of each of them without a CU, and those blocks form a SECOND round: the launch takes twice as
+// long, and the grouped weight gradient's pair partners stop being co-resident.  With a reserve of r the grids are sized for (CUs - r): one round, every
+// block 256 / (256 - r) longer.  Decoding (no collectives beside it) sizes its grid from device_cu_count().
+extern "C" int sam_get_cu_reserve(void);
+inline int grid_cu_count() {
+  const int n = device_cu_count(), r = sam_get_cu_reserve();
+  return (r > 0 && n - r >= 8) ? n - r : n;
+}
+
 // 8-wave persistent kernels (gemm8.hip).  tile: 0 = heuristic, 1192 / 1256 / 1448 = force the 192x192 / 256x256 / 192x256 configuration.
 // Returns SAM_ERR_UNSUPPORTED (without touching the error string) when the problem or the (layout, epilogue, output type) combination
 // has no instance there: the caller then uses the 4-wave kernels.

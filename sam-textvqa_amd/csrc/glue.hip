@@ -54,7 +54,45 @@ __global__ __launch_bounds__(NT) void ge_u8_kernel(const long long* x, long long
   if (i < n) out[i] = x[i] >= thr ? 1 : 0;
 }
 
+// out[r, c] = a[r, c] * b[r, c] (mode 0) | a[r, c] + vec[c] (mode 1) | a[r, c] * vec[c] (mode 2): bf16 rows, fp32 arithmetic, one rounding.  Four columns per thread.
+template <int MODE>
+__global__ __launch_bounds__(NT) void rowvec_kernel(const bf16_t* a, long long lda, const bf16_t* b, long long ldb, const float* vec, bf16_t* out, long long ldo, long long rows, int cols4) {
+  const long long total = rows * cols4;
+  for (long long e = (long long)blockIdx.x * NT + threadIdx.x; e < total; e += (long long)gridDim.x * NT) {
+    const long long r = e / cols4;
+    const int c = (int)(e - r * cols4) * 4;
+    const uint2 u = *reinterpret_cast<const uint2*>(a + r * lda + c);
+    float v[4] = {bf_lo(u.x), bf_hi(u.x), bf_lo(u.y), bf_hi(u.y)};
+    if (MODE == 0) {
+      const uint2 w = *reinterpret_cast<const uint2*>(b + r * ldb + c);
+      v[0] *= bf_lo(w.x); v[1] *= bf_hi(w.x); v[2] *= bf_lo(w.y); v[3] *= bf_hi(w.y);
+    } else {
+      const float4 f = *reinterpret_cast<const float4*>(vec + c);
+      if (MODE == 1) { v[0] += f.x; v[1] += f.y; v[2] += f.z; v[3] += f.w; }
+      else { v[0] *= f.x; v[1] *= f.y; v[2] *= f.z; v[3] *= f.w; }
+    }
+    uint2 o; o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(out + r * ldo + c) = o;
+  }
+}
+
 }  // namespace
+
+extern "C" int sam_rowvec_bf16(int mode, const void* a, int64_t lda, const void* b, int64_t ldb, const float* vec, void* out, int64_t ldo, int64_t rows, int cols, void* stream) {
+  SAM_REQUIRE(a && out && rows > 0 && cols > 0 && cols % 4 == 0 && lda % 4 == 0 && ldo % 4 == 0 && (uintptr_t)a % 8 == 0 && (uintptr_t)out % 8 == 0,
+              "sam_rowvec_bf16: null / empty operand, or width / strides / pointers not multiples of 4 elements");
+  SAM_REQUIRE(mode >= 0 && mode <= 2, "sam_rowvec_bf16: mode %d (0 = a * b, 1 = a + vec, 2 = a * vec)", mode);
+  SAM_REQUIRE(mode == 0 ? (b && ldb % 4 == 0 && (uintptr_t)b % 8 == 0) : (vec && (uintptr_t)vec % 16 == 0), "sam_rowvec_bf16: mode %d needs %s", mode, mode == 0 ? "b (8-byte aligned rows)" : "vec (fp32, 16-byte aligned)");
+  const long long total = rows * (cols / 4);
+  long long nb = (total + (long long)NT * 4 - 1) / ((long long)NT * 4);
+  nb = nb < 1 ? 1 : (nb > 4096 ? 4096 : nb);
+  const hipStream_t st = (hipStream_t)stream;
+  if (mode == 0) rowvec_kernel<0><<<dim3((unsigned)nb), dim3(NT), 0, st>>>((const bf16_t*)a, lda, (const bf16_t*)b, ldb, vec, (bf16_t*)out, ldo, rows, cols / 4);
+  else if (mode == 1) rowvec_kernel<1><<<dim3((unsigned)nb), dim3(NT), 0, st>>>((const bf16_t*)a, lda, nullptr, 0, vec, (bf16_t*)out, ldo, rows, cols / 4);
+  else rowvec_kernel<2><<<dim3((unsigned)nb), dim3(NT), 0, st>>>((const bf16_t*)a, lda, nullptr, 0, vec, (bf16_t*)out, ldo, rows, cols / 4);
+  SAM_LAUNCH_CHECK();
+  return SAM_OK;
+}
 
 extern "C" int sam_copy_blocks(const sam_copy_desc* descs, int count, void* stream) {
   SAM_REQUIRE(descs && count >= 1 && count <= MAXD, "sam_copy_blocks: 1..%d blocks per launch", MAXD);

@@ -12,12 +12,11 @@ import os
 from collections import Counter
 
 import torch
-import torch.nn.functional as F
 from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, cat_rows, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm,
+from .autograd import (BF16, AttentionFn, DenseDropoutResLnFn, DenseGeluFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, cat_rows, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm,
                        linear)
 from .params import prepare
 from .registry import registry
@@ -127,9 +126,10 @@ class BertSelfOutput(_HipModule):
         self.dropout_p = config.hidden_dropout_prob
 
     def forward(self, hidden_states, input_tensor):
+        """LayerNorm(dropout(dense(hidden_states)) + input_tensor): one GEMM with the bias + dropout + residual epilogue and the LayerNorm kernel -- the
+        fused encoder layer's own launches (autograd.DenseDropoutResLnFn); nothing here is computed by torch"""
         self._ready()
-        h = dropout(linear(hidden_states.to(BF16), self.dense), self.dropout_p, self.training)
-        return layer_norm(h + input_tensor.to(BF16), self.LayerNorm)
+        return DenseDropoutResLnFn.apply(hidden_states, input_tensor, self, float(self.dropout_p) if self.training else 0.0)
 
 
 class BertIntermediate(_HipModule):
@@ -141,7 +141,7 @@ class BertIntermediate(_HipModule):
 
     def forward(self, hidden_states):
         self._ready()
-        return F.gelu(linear(hidden_states.to(BF16), self.dense))
+        return DenseGeluFn.apply(hidden_states, self, torch.is_grad_enabled())          # erf-GELU in the GEMM's epilogue (autograd.DenseGeluFn)
 
 
 class BertOutput(_HipModule):

@@ -629,6 +629,26 @@ def copy_blocks(blocks):
         capi.call("sam_copy_blocks", C.cast(arr, C.c_void_p), len(part), capi.stream_handle())
 
 
+def rowvec(mode, a, b=None, vec=None):
+    """bf16 rows: "mul" a * b | "add_vec" a + vec[cols] | "mul_vec" a * vec[cols] (vec fp32) -> bf16 [rows, cols] (include/sam_hip.h: sam_rowvec_bf16)"""
+    m = {"mul": 0, "add_vec": 1, "mul_vec": 2}[mode]
+    _chk(a, BF16, "a")
+    if a.dim() != 2 or a.stride(1) != 1:
+        raise capi.SamHipError("rowvec: a must be 2-D with contiguous rows")
+    if m == 0:
+        _chk(b, BF16, "b")
+        if b.shape != a.shape or b.stride(1) != 1:
+            raise capi.SamHipError("rowvec mul: b must have a's shape and contiguous rows")
+    else:
+        _chk(vec, torch.float32, "vec")
+        if vec.numel() != a.shape[1] or not vec.is_contiguous():
+            raise capi.SamHipError("rowvec: vec must be a contiguous fp32 vector of a's width")
+    out = torch.empty(a.shape, dtype=BF16, device=a.device)
+    capi.call("sam_rowvec_bf16", m, capi.ptr(a), a.stride(0), capi.ptr(b), b.stride(0) if b is not None else 0, capi.ptr(vec), capi.ptr(out), out.stride(0),
+              a.shape[0], a.shape[1], capi.stream_handle(), meta=dict(kernel="rowvec", bytes=2.0 * a.numel() * (3 if m == 0 else 2)))
+    return out
+
+
 def ge_u8(x, threshold):
     """uint8 [n] = x >= threshold for an int64 tensor (token types of the previous predictions, sa_m4c.py:936)"""
     _chk(x, torch.int64, "x")
@@ -713,6 +733,23 @@ def step_advance(rng_state, offset_stride, step_counter, base_lrs, dev_sched, be
     sc.beta1, sc.beta2 = float(betas[0]), float(betas[1])
     capi.call("sam_step_advance", capi.ptr(rng_state), int(offset_stride), capi.ptr(step_counter), C.cast(C.pointer(sc), C.c_void_p), capi.ptr(dev_sched),
               capi.stream_handle())
+
+
+def set_cu_reserve(n):
+    """CUs withheld from every persistent grid of the training step (include/sam_hip.h: sam_set_cu_reserve); returns the value in force (a multiple of 8).
+    Grids already captured into a hipGraph keep what they were captured with: set it BEFORE the Trainer's first captured step."""
+    capi.call("sam_set_cu_reserve", int(n))
+    return cu_reserve()
+
+
+def cu_reserve():
+    return int(capi.call("sam_get_cu_reserve"))
+
+
+def debug_cu_hog(blocks, microseconds, stream=None):
+    """measurement aid: `blocks` workgroups each holding one CU (64 KB of LDS) for `microseconds` on `stream` (default: the current one)"""
+    st = capi.stream_handle() if stream is None else capi.C.c_void_p(stream.cuda_stream)
+    capi.call("sam_debug_cu_hog", int(blocks), float(microseconds), st)
 
 
 def set_rng_state(state):

@@ -26,6 +26,10 @@ import torch.distributed as dist
 from . import rccl
 
 CAPTURE_ERROR_MODE = "thread_local"
+# CUs the step's persistent grids leave to RCCL's channel kernels when the job spans more than one rank (Trainer; csrc/gemm_common.h: grid_cu_count), and the
+# cap init_distributed puts on RCCL's channel count so that the collectives never want more CUs than that (one channel = one 256-thread block = one CU, since
+# the step's blocks fill a CU's registers / LDS).  The exchange is 292 MB per ~6 ms step, ~50 GB/s of algorithm bandwidth: a fraction of what 32 channels move.
+DEFAULT_CU_RESERVE = 32
 
 
 def quiesce_before_capture():
@@ -89,6 +93,13 @@ class GradReducer:
         self.regions = []
         self.barrier_names, self.barrier_regions = set(), []
         self.comm = self._resolve_comm()
+        # SAM_EMULATE_COMM="<channels>:<GB/s>" (1-rank groups only, a measurement aid): every collective of the step is followed, on the SAME stream, by a
+        # stand-in for what it would be on N GPUs -- <channels> workgroups holding a CU each (ops.debug_cu_hog) for bytes / <GB/s> -- so that one GPU shows
+        # what RCCL's channel kernels cost the persistent kernels they run beside, in the captured step's own stream structure (tools/bench_cu_reserve.py)
+        self.emulate = None
+        if os.environ.get("SAM_EMULATE_COMM") and self.world_size == 1 and self.grad.is_cuda:
+            ch, gbps = os.environ["SAM_EMULATE_COMM"].split(":")
+            self.emulate = (int(ch), float(gbps))
         self.begin_step()
 
     def _resolve_comm(self):
@@ -228,6 +239,7 @@ class GradReducer:
         if self.payload == "fp32":
             if self.comm is not None:
                 rccl.all_reduce(self.comm, chunk)                      # on the current stream: the reducer's own under overlap, the step's otherwise
+                self._emulated(chunk.numel() * chunk.element_size())
                 return
             w = dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
@@ -247,6 +259,11 @@ class GradReducer:
         self._all_gather(out, mine)
         chunk.copy_(out[:n])
         self._keep.append((send, recv, mine, out))                     # (allocated on the caller's stream, used on the reducer's: held until finish())
+
+    def _emulated(self, nbytes):
+        if self.emulate is not None:
+            from . import ops
+            ops.debug_cu_hog(self.emulate[0], nbytes / (self.emulate[1] * 1e3))      # (GB/s = bytes per ns * 1; us = bytes / (GB/s * 1e3))
 
     def _all_gather(self, out, t):
         if self.comm is not None:
@@ -382,6 +399,9 @@ def init_distributed():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
+        if backend == "nccl" and world > 1:
+            # (a user's own NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS are left alone; with them, set SAM_DP_CU_RESERVE to match)
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SAM_DP_CU_RESERVE", str(DEFAULT_CU_RESERVE)))
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)

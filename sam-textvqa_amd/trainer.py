@@ -48,6 +48,18 @@ class Trainer:
         if reducer is None and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SAM_FORCE_DIST") == "1"):
             reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range(), overlap=overlap)      # (overlap=False: buckets leave after the backward, an A/B)
         self.reducer = reducer
+        # CU head-room for the collectives (csrc/gemm_common.h: grid_cu_count).  Every hot kernel of the step is persistent with one block per CU; RCCL's channel
+        # blocks need CUs of their own while the buckets leave underneath the BACKWARD pass (292 MB per step), and without a reserve the blocks they displace form
+        # a second launch round.  Under a reducer that spans more than one rank the persistent grids launched between the loss and reducer.finish() give up
+        # `cu_reserved` CUs (SAM_DP_CU_RESERVE, default parallel.DEFAULT_CU_RESERVE = the number init_distributed caps RCCL's channels at); the forward pass, which
+        # has no collective beside it, keeps the whole chip.  An explicit SAM_CU_RESERVE is the floor for every launch of the process.  What the reserve costs and
+        # buys: DESIGN.md section 6, profiles/r6_cu_reserve.txt.
+        self._cu_base = ops.cu_reserve() if self.flat.flat.is_cuda else 0
+        self.cu_reserved = self._cu_base
+        multi = reducer is not None and (reducer.world_size > 1 or (reducer.force and "SAM_DP_CU_RESERVE" in os.environ))
+        if self.flat.flat.is_cuda and multi:
+            want = int(os.environ.get("SAM_DP_CU_RESERVE", parallel.DEFAULT_CU_RESERVE))
+            self.cu_reserved = max(self._cu_base, want - want % 8)
         rank = dist.get_rank() if dist.is_initialized() else 0
         if reducer is not None and dist.is_initialized():
             # replicas must START identical and nothing re-synchronises them later: rank 0's masters and optimizer state go to everyone
@@ -333,11 +345,15 @@ class Trainer:
         if defer_ln:
             self._set_ln_defer(True)
         DeferredWgrads.late_armed = True                        # (this method joins the late stream below, before anything reads a gradient)
+        if self.cu_reserved != self._cu_base:
+            ops.set_cu_reserve(self.cu_reserved)                # host-side state read at launch (and at capture): the backward's persistent grids leave CUs to the collectives
         try:
             if self._grad_one is None or self._grad_one.device != loss.device:
                 self._grad_one = torch.ones((), dtype=loss.dtype, device=loss.device)
             loss.backward(self._grad_one)                       # (a resident 1.0: autograd would fill a fresh one every step)
         except BaseException:
+            if self.cu_reserved != self._cu_base:
+                ops.set_cu_reserve(self._cu_base)
             # whatever the LayerNorm backwards queued points into workspaces of a backward pass that no longer exists (under capture: into the
             # graph's private pool): drop it, or the next step's flush would reduce stale partial sums into dgamma / dbeta / dbias
             self._ln_clear()
@@ -365,6 +381,8 @@ class Trainer:
             if timing:
                 e1.record()
                 self._comm_events.append((e0, e1))
+        if self.cu_reserved != self._cu_base:
+            ops.set_cu_reserve(self._cu_base)                   # gradient norm, Adam and the next forward: the whole chip again
         ops.sumsq(flat.grad, self.gnorm_sq, sparse=self.sparse)     # global norm AFTER the all-reduce, as the reference clips reduced grads
         if pipelined:
             # t = ++step counter and the learning rates / bias corrections of THIS step's update, for the Adam pieces at the head of the next replay

@@ -495,3 +495,27 @@ def test_attention_fp16_block_scaling_is_scale_free(qs, ks, vs, ds):
             assert (got[:, j] == 0).all(), nm
         else:
             assert_close_bf16(got[:, j], gref[:, j], name="%s (scaled inputs)" % nm)
+
+
+def test_fused_backward_grid_with_cus_withheld_is_bit_identical():
+    """sam_set_cu_reserve: the persistent one-pass backward walks more heads per block on fewer blocks; which block owns a head changes nothing"""
+    ops = _ops()
+    B, H, hd = 40, 12, 64
+    pr = make_problem(B, 20, 100, 50, 12, seed=4)
+    N = pr["N"]
+    base = ops.mask_bits_prefix_lm(pr["key_valid"].to(torch.uint8).cuda(), pr["n_dec"])
+    allow_bits = ops.mask_bits_spatial(base, pr["adj"].cuda(), pr["T"], H, (1, 2))
+    g = torch.Generator().manual_seed(8)
+    qkv = (torch.randn(B * N, 3 * H * hd, generator=g) * 1.5).to(torch.bfloat16).cuda()
+    dout = torch.randn(B * N, H * hd, generator=g).to(torch.bfloat16).cuda()
+    scale = 1.0 / math.sqrt(hd)
+    out, lse2, keep_bits, out_lo = ops.attn_fwd(qkv, allow_bits, B, H, scale, 0.1, seed=99, offset=2, want_residual=True)
+    assert ops.set_cu_reserve(0) == 0
+    full = ops.attn_bwd(dout, qkv, lse2, allow_bits, keep_bits, B, H, scale, 0.1, out=out, out_lo=out_lo).clone()
+    try:
+        for reserve in (32, 96):
+            assert ops.set_cu_reserve(reserve) == reserve
+            part = ops.attn_bwd(dout, qkv, lse2, allow_bits, keep_bits, B, H, scale, 0.1, out=out, out_lo=out_lo)
+            assert torch.equal(full, part), reserve
+    finally:
+        ops.set_cu_reserve(0)

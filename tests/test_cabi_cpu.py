@@ -34,11 +34,18 @@ def test_ctypes_binding_covers_the_header():
     assert declared <= bound, "unbound entry points: %s" % sorted(declared - bound)
     assert bound <= set(header_functions()), "bound but undeclared: %s" % sorted(bound - set(header_functions()))
     l = _capi.lib()
-    assert l.sam_abi_version() == 7
+    assert l.sam_abi_version() == 8
     import sam_textvqa_amd._build as b
     assert l.sam_build_digest().decode() == b._digest()          # the binary that is loaded is the one built from the sources in the tree
     assert _capi.call("sam_attn_words_per_row", 182) == 6 and _capi.call("sam_attn_words_per_row", 20) == 1
     assert _capi.call("sam_attn_words_per_row", 350) == 12 and _capi.call("sam_attn_words_per_row", 385) == -1
+    # CUs withheld from persistent grids: a multiple of 8, bounded, host-side state only (no GPU needed)
+    was = _capi.call("sam_get_cu_reserve")
+    _capi.call("sam_set_cu_reserve", 37)
+    assert _capi.call("sam_get_cu_reserve") == 32
+    with pytest.raises(_capi.SamHipError):
+        _capi.call("sam_set_cu_reserve", 200)
+    _capi.call("sam_set_cu_reserve", was)
 
 
 def test_gemm_desc_layout_matches_header_field_order():

@@ -189,6 +189,7 @@ def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
     assert out["rccl_ranks_seen"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
     assert out["exposed_comm_ms"] >= 0.0 and "every rank" in out["exposed_comm_source"]
     assert out["dp_transport"] == "process-group" and out["step_mode"] == "eager launches"
+    assert out["cu_reserved"] == 32          # a reducer spanning > 1 rank: the persistent grids leave CUs to the collectives (Trainer; parallel.DEFAULT_CU_RESERVE)
     assert abs(out["value"] - 128 * 3 / (out["ms_per_step"] * 3e-3)) <= 0.02 * out["value"]
 
 
