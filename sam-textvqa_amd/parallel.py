@@ -26,10 +26,11 @@ import torch.distributed as dist
 from . import rccl
 
 CAPTURE_ERROR_MODE = "thread_local"
-# CUs the step's persistent grids leave to RCCL's channel kernels when the job spans more than one rank (Trainer; csrc/gemm_common.h: grid_cu_count), and the
-# cap init_distributed puts on RCCL's channel count so that the collectives never want more CUs than that (one channel = one 256-thread block = one CU, since
-# the step's blocks fill a CU's registers / LDS).  The exchange is 292 MB per ~6 ms step, ~50 GB/s of algorithm bandwidth: a fraction of what 32 channels move.
-DEFAULT_CU_RESERVE = 32
+# CUs the backward's persistent grids leave to RCCL's channel kernels when the job spans more than one rank (Trainer; csrc/gemm_common.h: grid_cu_count), unless
+# SAM_DP_CU_RESERVE says otherwise.  0 = off, the measured choice: on one GPU with the collectives emulated inside the captured step (tools/bench_cu_reserve.py,
+# profiles/r6_cu_reserve.txt) a reserve of 16 / 32 costs the backward 0.2 ms per step (fewer CUs per launch, coarser tile rounds) and saves the same 0.2-0.3 ms
+# (kernels beside a 32-channel collective run 1.3-1.6x longer for the ~0.9 ms per step that collectives and backward kernels overlap): no net gain.
+DEFAULT_CU_RESERVE = 0
 
 
 def quiesce_before_capture():
@@ -135,7 +136,8 @@ class GradReducer:
         order).  `cut`: a forced boundary (the low end of the registered regions): a bucket straddling it would mix gradients that are final
         early (encoder layers) with ones that are final last (everything below) and could only leave at finish()."""
         n, per = self.grad.numel(), self.per_bucket
-        edges = sorted({0, n, self.sparse_lo, self.sparse_hi} | ({cut} if cut is not None and 0 < cut < n else set()), reverse=True)
+        cuts = set() if cut is None else ({cut} if isinstance(cut, int) else set(cut))
+        edges = sorted({0, n, self.sparse_lo, self.sparse_hi} | {c for c in cuts if 0 < c < n}, reverse=True)
         self.buckets = []
         for top, bottom in zip(edges[:-1], edges[1:]):
             if bottom >= self.sparse_lo and top <= self.sparse_hi:
@@ -157,7 +159,12 @@ class GradReducer:
         if self.regions and self.regions[0][1] != self.grad.numel():
             raise ValueError("the highest gradient region must end at the end of the flat buffer")
         if self.regions:
-            self._build_buckets(cut=min(lo for lo, _ in self.regions))
+            # Every region boundary is a bucket boundary (SAM_BUCKET_PER_REGION=0: only the low end of the regions, as rounds 2-5 had it).  A 64 MB bucket
+            # spans 2.3 encoder layers (28.3 MB each) and leaves only when ALL of them are final -- with the weight gradients going out in layer pairs the first
+            # bucket left after FOUR of the MMT's six layers (profiles/r6_dp_timeline.txt: 1.9 ms into a 3.8 ms backward) and three of five buckets after
+            # its end.  One bucket per region leaves with its region: 12 collectives of <= 28 MB instead of 5 of 64 MB, the first two at the first pair.
+            per_region = os.environ.get("SAM_BUCKET_PER_REGION", "1") != "0"
+            self._build_buckets(cut={lo for lo, _ in self.regions} if per_region else min(lo for lo, _ in self.regions))
         ids = [0] * len(ranges)
         for pos, i in enumerate(order):
             ids[i] = pos
@@ -399,9 +406,8 @@ def init_distributed():
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
         kw = {"device_id": torch.device("cuda", local)} if backend == "nccl" else {}
-        if backend == "nccl" and world > 1:
-            # (a user's own NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS are left alone; with them, set SAM_DP_CU_RESERVE to match)
-            os.environ.setdefault("NCCL_MAX_NCHANNELS", os.environ.get("SAM_DP_CU_RESERVE", str(DEFAULT_CU_RESERVE)))
+        # (RCCL's channel count is left to RCCL: NCCL_MAX_NCHANNELS / NCCL_MIN_NCHANNELS are the user's; a reserve -- SAM_DP_CU_RESERVE -- should not be smaller
+        # than the channels RCCL ends up using, or the blocks beyond it displace persistent blocks all the same.  DESIGN.md section 6.)
         dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local)

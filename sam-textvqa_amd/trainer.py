@@ -46,7 +46,8 @@ class Trainer:
         self.schedule = schedule or {}
         dist = parallel.dist
         if reducer is None and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("SAM_FORCE_DIST") == "1"):
-            reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range(), overlap=overlap)      # (overlap=False: buckets leave after the backward, an A/B)
+            reducer = parallel.GradReducer(self.flat.grad, sparse_range=self._sparse_table_range(), overlap=overlap,      # (overlap=False: buckets leave after the backward, an A/B)
+                                           bucket_bytes=int(float(os.environ.get("SAM_BUCKET_MB", "64")) * (1 << 20)))
         self.reducer = reducer
         # CU head-room for the collectives (csrc/gemm_common.h: grid_cu_count).  Every hot kernel of the step is persistent with one block per CU; RCCL's channel
         # blocks need CUs of their own while the buckets leave underneath the BACKWARD pass (292 MB per step), and without a reserve the blocks they displace form

@@ -219,3 +219,29 @@ def test_capture_agreement_and_scalar_reduce_gloo_world2():
     from sam_textvqa_amd import parallel
     assert parallel.agree(True) is True and parallel.agree(False) is False      # no group: the local answer
     assert parallel.CAPTURE_ERROR_MODE == "thread_local"
+
+
+def test_buckets_are_cut_at_every_region_boundary(monkeypatch):
+    """round 6: one bucket per finality region (a region larger than bucket_bytes is subdivided), so a layer's gradients leave when THAT layer is final -- a bucket
+    spanning 2.3 layers used to wait for all of them.  Host logic only: no process group, no GPU."""
+    from sam_textvqa_amd.parallel import GradReducer
+    grad = torch.zeros(1000)
+    red = GradReducer(grad, bucket_bytes=4 * 300, sparse_range=(100, 250))
+    ids = red.register_regions([(820, 1000), (640, 820), (250, 640), (40, 100)])          # the row-sparse table sits between the last two
+    assert ids == [0, 1, 2, 3]
+    assert red.buckets == [(820, 1000), (640, 820), (340, 640), (250, 340), (40, 100), (0, 40)]
+    red.begin_step()
+    red.mark_done(1)                       # out of order: nothing leaves before region 0 is final
+    assert red.next_bucket == 0
+    red.mark_done(0)
+    assert red.next_bucket == 2            # ... then both regions' buckets
+    red.mark_done(2)
+    assert red.next_bucket == 4            # the subdivided region: both of its buckets
+    red.mark_done(3)
+    assert red.next_bucket == 5
+    red.finish()
+    assert red.late_buckets == 1           # [0, 40) has no region: it leaves at finish()
+    monkeypatch.setenv("SAM_BUCKET_PER_REGION", "0")
+    old = GradReducer(torch.zeros(1000), bucket_bytes=4 * 300, sparse_range=(100, 250))
+    old.register_regions([(820, 1000), (640, 820), (250, 640), (40, 100)])
+    assert old.buckets == [(700, 1000), (400, 700), (250, 400), (40, 100), (0, 40)]      # rounds 2-5: only the low end of the regions is a forced cut

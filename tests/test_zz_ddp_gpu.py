@@ -173,7 +173,7 @@ def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
     import sys
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1", SAM_BENCH_EAGER_COMM_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1", SAM_BENCH_EAGER_COMM_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAM_DP_CU_RESERVE="32")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAM_FORCE_DIST", "SAM_REDUCER_CHECK"):
         env.pop(k, None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
@@ -189,7 +189,7 @@ def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
     assert out["rccl_ranks_seen"] == 2 and out["config"]["global_batch"] == 128 and out["config"]["parallelism"] == "dp2"
     assert out["exposed_comm_ms"] >= 0.0 and "every rank" in out["exposed_comm_source"]
     assert out["dp_transport"] == "process-group" and out["step_mode"] == "eager launches"
-    assert out["cu_reserved"] == 32          # a reducer spanning > 1 rank: the persistent grids leave CUs to the collectives (Trainer; parallel.DEFAULT_CU_RESERVE)
+    assert out["cu_reserved"] == 32          # SAM_DP_CU_RESERVE: under a reducer spanning > 1 rank the backward's persistent grids leave CUs to the collectives
     assert abs(out["value"] - 128 * 3 / (out["ms_per_step"] * 3e-3)) <= 0.02 * out["value"]
 
 
