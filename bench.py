@@ -79,12 +79,19 @@ def profile_step(trainer, batch, reps=5):
             key += "@M=%d" % meta["shape"][0]             # MMT-size (11648 rows) and TextBert / head-size launches of one symbol are different regimes
         elif key.startswith("attn_") and meta.get("shape"):
             key += "@N=%d" % meta["shape"][1]             # 182-token MMT launches vs TextBert's 20-token ones
-        a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0))
+        a = agg.setdefault(key, dict(calls=0, ms=0.0, flops=0.0, bytes=0.0, survey_bytes=0.0))
         dt = max(statistics.median(r[j][2] for r in runs) - overhead_ms, 0.0)
         a["calls"] += 1
         a["ms"] += dt
         a["flops"] += meta.get("flops", 0.0)
         a["bytes"] += meta.get("bytes", 0.0)
+        if key.startswith("attn_") and meta.get("shape"):
+            # SURVEY.md 8(d)'s algorithmic bytes of the attention kernel, on what the kernel itself reads and writes: forward Q, K, V read + O written (bf16), the
+            # key-valid row and the log-sum-exps; backward q, k, v, o, dO read + dq, dk, dv written.  (The implementation's own count -- `bytes` -- also has the
+            # allow / keep bit planes and the bf16 residual of O that the one-pass backward takes delta from; SURVEY's 0.27 MB / sample int8 relation tensor is
+            # read by the mask packer once per batch, not by this kernel.)
+            b_, n_, h_ = meta["shape"]
+            a["survey_bytes"] += b_ * ((8 if "bwd" in key else 4) * n_ * h_ * 64 * 2.0 + n_ + h_ * n_ * 4.0)
         if key.startswith("gemm") and meta.get("flops", 0.0) >= 5e9:          # the big launches again, by shape (TextBert's 1280-row GEMMs
             b = agg.setdefault("@shapes", {}).setdefault((key, tuple(meta.get("shape", ()))), dict(calls=0, ms=0.0, flops=0.0))      # share the symbol rows above)
             b["calls"] += 1
@@ -286,6 +293,9 @@ def roofline_from(agg):
             extra[key] = dict(bound="hbm", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s", frac=round(ach / PEAK_HBM_GBS, 4),
                               traffic=pmc_traffic(key), avg_launch_us=round(1e3 * a["ms"] / a["calls"], 2), launches_per_step=a["calls"],
                               bytes_per_launch=a["bytes"] / a["calls"])
+            if a.get("survey_bytes"):
+                sv = a["survey_bytes"] / (a["ms"] * 1e-3) / 1e9
+                extra[key].update(survey_bytes_per_launch=a["survey_bytes"] / a["calls"], achieved_on_survey_bytes=round(sv, 1), frac_on_survey_bytes=round(sv / PEAK_HBM_GBS, 4))
     by_shape = [dict(kernel=k, shape=list(sh), calls=b["calls"], avg_us=round(1e3 * b["ms"] / b["calls"], 2), tflops=round(b["flops"] / (b["ms"] * 1e-3) / 1e12, 1))
                 for (k, sh), b in sorted(shapes.items(), key=lambda kv: -kv[1]["ms"])]
     extra["gemm_by_shape"] = by_shape[:16]
