@@ -405,6 +405,12 @@ typedef struct sam_decode_desc {
 int64_t sam_greedy_decode_ws_bytes(int B, int S, int n_layers);
 int sam_greedy_decode_steps(const sam_decode_desc* desc, void* ws, int64_t ws_bytes, void* stream);
 
+/* ---- `output_attentions` (sam/sa_m4c.py:600-609; BertSpatialEncoder 765-769): attention_probs [B, H, N, N] fp32, rebuilt from what the fused forward saved ----
+ * P = allow ? exp2(scale * log2(e) * <q, k> - lse2) : 0, times keep / (1 - p_drop) where the forward dropped (keep: its bit planes, NULL = no dropout), times
+ * head_scale[h] (head_mask as one factor per head, :591-592; NULL = none).  Fully masked rows are exact zeros (:574-584).  Off the training path. */
+int sam_attn_probs(const void* qkv, const uint32_t* allow, int64_t allow_stride_b, int64_t allow_stride_h, const float* lse2, const uint32_t* keep,
+                   const float* head_scale, int B, int N, int H, int head_dim, float scale, float p_drop, float* out, void* stream);
+
 /* ---- glue (csrc/glue.hip): up to 8 strided block copies / casts / accumulations / zero-fills in ONE launch ----
  * block q: dst[b, i, :cols] (+)= src[b, i, :cols] for b < batches, i < rows; element (b, i, c) at b * batch_stride + i * row_stride + c; src NULL = zeros;
  * src_f32 / dst_f32: 1 = fp32, 0 = bf16 (converted with round-to-nearest-even); accumulate: dst += src.  cols and every stride multiples of 4 elements.

@@ -90,6 +90,7 @@ SIGNATURES = {
     "sam_copy_blocks": [C.c_void_p, _i, _vp],
     "sam_ge_u8": [_vp, _i64, _i64, _vp, _vp],
     "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
+    "sam_attn_probs": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "sam_rowvec_bf16": [_i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i, _vp],
     "sam_set_cu_reserve": [_i],
     "sam_get_cu_reserve": [],

@@ -834,7 +834,7 @@ class AttentionFn(Function):
     """stand-alone fused attention (module-level SpatialBertSelfAttention / BertSelfAttention API)"""
 
     @staticmethod
-    def forward(ctx, qkv, allow, batch, heads, scale, p_drop):
+    def forward(ctx, qkv, allow, batch, heads, scale, p_drop, side=None):
         qkv = qkv.contiguous()
         seed = dropout_clock.next()
         if qkv.shape[0] // batch <= ops.attn_bwd_fused_max_n() and os.environ.get("SAM_ATTN_BWD_FUSED", "1") != "0":
@@ -843,13 +843,46 @@ class AttentionFn(Function):
             (out, lse2, keep), out_lo = ops.attn_fwd(qkv, allow, batch, heads, scale, p_drop, *seed), None
         ctx.save_for_backward(qkv, lse2, keep, allow, out, out_lo)
         ctx.cfg = (batch, heads, scale, p_drop)
+        if side is not None:         # `output_attentions`: what ops.attn_probs rebuilds the probabilities from
+            side.update(qkv=qkv, lse2=lse2, keep=keep)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, lse2, keep, allow, out, out_lo = ctx.saved_tensors
         batch, heads, scale, p_drop = ctx.cfg
-        return ops.attn_bwd(dout.to(BF16).contiguous(), qkv, lse2, allow, keep, batch, heads, scale, p_drop, out=out, out_lo=out_lo), None, None, None, None, None
+        return ops.attn_bwd(dout.to(BF16).contiguous(), qkv, lse2, allow, keep, batch, heads, scale, p_drop, out=out, out_lo=out_lo), None, None, None, None, None, None
+
+
+class RowScaleFn(Function):
+    """ctx * vec over the model dimension (head_mask as one factor per head, broadcast over the head's columns: probs * head_mask before P V is the same as scaling the
+    head's context columns, sa_m4c.py:591-594); backward: the same scaling of the gradient.  vec: fp32 [D], no gradient."""
+
+    @staticmethod
+    def forward(ctx, x, vec):
+        ctx.save_for_backward(vec)
+        return ops.rowvec("mul_vec", x.contiguous(), vec=vec)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (vec,) = ctx.saved_tensors
+        return ops.rowvec("mul_vec", dy.to(BF16).contiguous(), vec=vec), None
+
+
+class HeadBiasFn(Function):
+    """context_layer + biases(0) (`use_bias`, sa_m4c.py:439-443, 600-603): one fp32 row added to every context row; backward: the gradient passes through,
+    the bias row receives its column sums (sam_colsum_bf16, accumulated into the parameter's .grad in flat storage)."""
+
+    @staticmethod
+    def forward(ctx, x, table):
+        ctx.table = table
+        return ops.rowvec("add_vec", x.contiguous(), vec=table.detach().reshape(-1).float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.to(BF16).contiguous()
+        ops.colsum(dy, ctx.table.grad.view(-1), accumulate=True)
+        return dy, None
 
 
 # ------------------------------------------------------------------------------------------------ pointer net / loss

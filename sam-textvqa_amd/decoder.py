@@ -307,6 +307,8 @@ class DecodeSession:
             d3, d = wqkv.shape
             if d != 768 or inter.dense.weight.shape[0] != 3072 or att.attention_head_size != 64 or d3 != 3 * d:
                 return False
+            if getattr(att, "use_bias", False):         # head biases (sa_m4c.py:600-603) are not a phase of the persistent kernel: the per-kernel step adds them (_layer_tail)
+                return False
             srcs += [wqkv, _w(so.dense.weight), _w(inter.dense.weight), _w(out.dense.weight)]
             e1, e2 = float(so.LayerNorm.variance_epsilon), float(out.LayerNorm.variance_epsilon)
             if eps is None:

@@ -16,7 +16,7 @@ from torch import nn
 
 from . import _capi as capi
 from . import ops
-from .autograd import (BF16, AttentionFn, DenseDropoutResLnFn, DenseGeluFn, EmbedLayerNormFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, cat_rows, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm,
+from .autograd import (BF16, AttentionFn, DenseDropoutResLnFn, DenseGeluFn, EmbedLayerNormFn, HeadBiasFn, RowScaleFn, GradBarrierFn, InputEncoderFn, PrevPredFn, SeqRowsFn, cat_rows, dropout, PtrScoresFn, _fused_qkv, _w, encoder_layer, layer_norm,
                        linear)
 from .params import prepare
 from .registry import registry
@@ -85,9 +85,19 @@ def _to_rows(hidden_states):
     return x, b, n
 
 
-def _check_head_mask(head_mask):
-    if head_mask is not None and any(h is not None for h in (head_mask if isinstance(head_mask, (list, tuple)) else [head_mask])):
-        raise NotImplementedError("head_mask is always None on the reference path (sa_m4c.py:846); not supported by the fused kernels")
+def _head_scale(head_mask, n_heads, device):
+    """head_mask (sa_m4c.py:591-592: attention_probs * head_mask) as ONE factor per head -> fp32 [H] on the device, or None.  The reference never passes one
+    (`head_mask = [None] * num_hidden_layers`, :846; BertSpatialEncoder does not even hand it to its layers); the module-level API accepts what the BERT code
+    base uses: a tensor of H values in any broadcast shape ([H], [1, H, 1, 1], [H, 1, 1]).  Per-sample or per-position masks are refused."""
+    if head_mask is None:
+        return None
+    if isinstance(head_mask, (list, tuple)):
+        raise capi.SamHipError("head_mask: pass ONE layer's mask (a tensor of %d per-head factors), not the per-layer list" % n_heads)
+    hm = torch.as_tensor(head_mask)
+    if hm.numel() != n_heads:
+        raise NotImplementedError("head_mask of shape %s: only one factor per head (%d values, e.g. [H] or [1, H, 1, 1]) is supported; per-sample / per-position "
+                                  "masks would need the probabilities materialised" % (tuple(hm.shape), n_heads))
+    return hm.reshape(n_heads).to(device=device, dtype=torch.float32).contiguous()
 
 
 class _HipModule(nn.Module):
@@ -178,15 +188,26 @@ class BertSelfAttention(_HipModule):
         return self._attend(hidden_states, self._allow_bits(attention_mask), head_mask)
 
     def _attend(self, hidden_states, allow, head_mask):
+        """-> (context [B, N, D],) or (context, attention_probs fp32 [B, H, N, N]) under `output_attentions`.  The fused kernel never writes the probabilities:
+        they are rebuilt afterwards from its saved rows (ops.attn_probs) -- after dropout and head mask, as the reference returns them (sa_m4c.py:586-609),
+        detached from the graph (nothing upstream differentiates through them)."""
         self._ready()
-        _check_head_mask(head_mask)
-        if self.output_attentions:
-            raise NotImplementedError("output_attentions: the fused kernel never materialises the probabilities")
         x, b, n = _to_rows(hidden_states)
+        hs = _head_scale(head_mask, self.num_attention_heads, x.device)
         qkv = torch.cat([linear(x, self.query), linear(x, self.key), linear(x, self.value)], dim=1)
         p = self.dropout_p if self.training else 0.0
-        ctx = AttentionFn.apply(qkv, allow, b, self.num_attention_heads, 1.0 / math.sqrt(self.attention_head_size), p)
-        return (ctx.view(b, n, -1).to(hidden_states.dtype),)
+        scale = 1.0 / math.sqrt(self.attention_head_size)
+        side = {} if self.output_attentions else None
+        ctx = AttentionFn.apply(qkv, allow, b, self.num_attention_heads, scale, p, side)
+        if hs is not None:
+            ctx = RowScaleFn.apply(ctx, hs.repeat_interleave(self.attention_head_size).contiguous())
+        if getattr(self, "use_bias", False):
+            ctx = HeadBiasFn.apply(ctx, self.biases.weight)
+        out = (ctx.view(b, n, -1).to(hidden_states.dtype),)
+        if self.output_attentions:
+            with torch.no_grad():
+                out += (ops.attn_probs(side["qkv"], allow, side["lse2"], side["keep"], b, self.num_attention_heads, scale, p, head_scale=hs),)
+        return out
 
 
 class SpatialBertSelfAttention(BertSelfAttention):
@@ -215,7 +236,10 @@ class SpatialBertSelfAttention(BertSelfAttention):
         self.dropout_p = 0.0 if getattr(config, "no_drop", False) else config.attention_probs_dropout_prob
         self.use_bias = bool(getattr(config, "use_bias", False))
         if self.use_bias:
-            raise NotImplementedError("use_bias head biases (sa_m4c.py:439-443) are off in every shipped config; not implemented")
+            # sa_m4c.py:439-443: one learned row added to the merged context (state_dict key `biases.weight` [1, hidden]).  Off in every shipped config: such a
+            # layer runs through the module-by-module composition (_FusedLayer._run), not the single fused-layer node, and the persistent decoding kernel declines it
+            logging.getLogger(__name__).info("using head biases")
+            self.biases = nn.Embedding(1, config.hidden_size)
 
     def _allow_bits(self, attention_mask, spatial_adj_matrix=None):
         return as_allow(attention_mask).spatial(spatial_adj_matrix, self.max_seq_len, self.num_attention_heads, self.mask_quadrants)
@@ -252,9 +276,14 @@ class SpatialBertAttention(_HipModule):
 class _FusedLayer(_HipModule):
     def _run(self, hidden_states, allow, head_mask):
         self._ready()
-        _check_head_mask(head_mask)
-        if self.attention.self.output_attentions:
-            raise NotImplementedError("output_attentions is not available on the fused path")
+        att = self.attention.self
+        if head_mask is not None or att.output_attentions or getattr(att, "use_bias", False):
+            # the switches no shipped config turns on (off the path): module by module -- attention core (+ head factors, + head biases, + the
+            # probabilities), then BertSelfOutput / BertIntermediate / BertOutput, each on the library's kernels (autograd.DenseDropoutResLnFn / DenseGeluFn)
+            so = att._attend(hidden_states, allow, head_mask)
+            a = self.attention.output(so[0], hidden_states)
+            y = self.output(self.intermediate(a), a)
+            return (y.to(hidden_states.dtype),) + so[1:]
         x, b, n = _to_rows(hidden_states)
         y = encoder_layer(x, self, allow, b, self.training)
         return (y.view(b, n, -1).to(hidden_states.dtype),)
@@ -264,6 +293,8 @@ class _FusedLayer(_HipModule):
 def _layer_tail(layer, ctx, x):
     """everything of an encoder layer after the attention core, eval mode (no dropout), on a row subset: O-proj + LN, FFN + LN"""
     so, inter, out = layer.attention.output, layer.intermediate, layer.output
+    if getattr(layer.attention.self, "use_bias", False):          # context_layer + biases(0), sa_m4c.py:600-603
+        ctx = ops.rowvec("add_vec", ctx.contiguous(), vec=layer.attention.self.biases.weight.detach().reshape(-1).float().contiguous())
     # (gemm_ln: the LayerNorm rides on the GEMM's split-K reduction pass when there is one -- the few-row steps of the decoding loops -- and is its own launch otherwise)
     _, a, _, _ = ops.gemm_ln(ctx, _w(so.dense.weight), so.LayerNorm.weight, so.LayerNorm.bias, so.LayerNorm.variance_epsilon,
                              epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=so.dense.bias, residual=x)
@@ -329,9 +360,12 @@ class BertEncoder(_HipModule):
 
     def forward(self, hidden_states, attention_mask, head_mask=None):
         allow = as_allow(attention_mask)
+        all_att = ()
         for i, layer in enumerate(self.layer):
-            hidden_states = layer(hidden_states, allow, None if head_mask is None else head_mask[i])[0]
-        return (hidden_states,)
+            outs = layer(hidden_states, allow, None if head_mask is None else head_mask[i])
+            hidden_states = outs[0]
+            all_att += outs[1:]
+        return (hidden_states,) + ((all_att,) if all_att else ())
 
 
 class BertEmbeddings(_HipModule):
@@ -410,20 +444,25 @@ class BertSpatialEncoder(_HipModule):
     def forward(self, hidden_states, attention_mask, batch_dict, head_mask=None):
         allow = as_allow(attention_mask)
         normal, spatial = iter(self.normal_layers), iter(self.spatial_layers)
-        all_hidden = ()
+        all_hidden, all_att = (), ()
         for kind, mix in zip(self.layer_type_list, self.mix_list):
             if self.output_hidden_states:
                 all_hidden += (hidden_states,)
             if kind == "n":
-                hidden_states = next(normal)(hidden_states, allow)[0]
+                outs = next(normal)(hidden_states, allow)
             elif kind == "s":
-                hidden_states = next(spatial)(hidden_states, allow, self._adjacency_for(batch_dict, mix))[0]
+                outs = next(spatial)(hidden_states, allow, self._adjacency_for(batch_dict, mix))
             else:
                 raise ValueError   # 'i' layers are rejected by the reference as well (sa_m4c.py:751-752)
+            hidden_states = outs[0]
+            if self.output_attentions:
+                all_att += (outs[1],)
         assert next(normal, None) is None and next(spatial, None) is None
         outputs = (hidden_states,)
         if self.output_hidden_states:
             outputs += (all_hidden + (hidden_states,),)
+        if self.output_attentions:
+            outputs += (all_att,)          # last-layer hidden state, (all hidden states), (all attentions): sa_m4c.py:765-770
         return outputs
 
     def _adjacency_for(self, batch_dict, mix):

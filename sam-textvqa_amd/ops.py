@@ -151,6 +151,22 @@ def attn_fwd(qkv, allow, batch, n_heads, scale, p_drop=0.0, seed=0, offset=0, wa
     return out, lse2, keep
 
 
+def attn_probs(qkv, allow, lse2, keep, batch, n_heads, scale, p_drop=0.0, head_scale=None):
+    """the attention probabilities the fused forward did not materialise: fp32 [B, H, N, N] from its q | k rows, allow bits, log2-sum-exps and keep bits
+    (include/sam_hip.h: sam_attn_probs; sa_m4c.py:600-609 `output_attentions`)"""
+    _chk(qkv, BF16, "qkv"); _chk(allow, torch.int32, "allow"); _chk(lse2, torch.float32, "lse2")
+    rows, three_d = qkv.shape
+    n, d_model = rows // batch, three_d // 3
+    sh = 0 if allow.shape[1] == 1 else allow.stride(1)
+    if head_scale is not None:
+        _chk(head_scale, torch.float32, "head_scale")
+    out = torch.empty((batch, n_heads, n, n), dtype=torch.float32, device=qkv.device)
+    capi.call("sam_attn_probs", capi.ptr(qkv), capi.ptr(allow), allow.stride(0), sh, capi.ptr(lse2), capi.ptr(keep if p_drop > 0 else None), capi.ptr(head_scale),
+              batch, n, n_heads, d_model // n_heads, float(scale), float(p_drop if keep is not None else 0.0), capi.ptr(out), capi.stream_handle(),
+              meta=dict(kernel="attn_probs", bytes=4.0 * out.numel()))
+    return out
+
+
 def attn_fwd_rows(qkv, allow, batch, n_heads, scale, q_begin, out, lse2):
     """inference: recompute only query rows >= q_begin of `out` (bf16 [B*N, H*64], updated in place) against all keys of qkv"""
     _chk(qkv, BF16, "qkv"); _chk(allow, torch.int32, "allow"); _chk(out, BF16, "out")

@@ -267,6 +267,26 @@ def main():
                 arrays["grad." + pn] = np_(p.grad)
         save(name, **arrays)
 
+    # ---------------- SpatialBertLayer with the switches no shipped config turns on: use_bias (sa_m4c.py:439-443, 600-603), output_attentions (:604-609), head_mask (:591-592) ----
+    name, case = "layer_small_switches", C.LAYER_CASES["layer_small_c3"]
+    d = case["dims"]
+    cfg = BertConfig.from_dict(C.mmt_config_dict(d, ["s"], case["ctx"], case["quadrants"], use_bias=True, output_attentions=True))
+    layer = ref.SpatialBertLayer(cfg).eval()
+    C.fill_state_dict(layer, d["ws"], prefix=name + ".")
+    n = d["T"] + d["n_obj"] + d["n_ocr"] + d["n_dec"]
+    hidden = torch.from_numpy(C.det_uniform(name + ".hidden", (d["B"], n, d["D"]))).requires_grad_(True)
+    ext = torch.from_numpy(ext_mask_np(d))
+    adj = ref_adjacency(ref_su, C.case_boxes(name, d), case["ctx"])
+    head_mask = torch.from_numpy(C.det_uniform(name + ".head_mask", (1, d["H"], 1, 1), 0.25, 1.5))
+    head_mask[0, 3] = 0.0                                   # one head switched off
+    out, probs = layer(hidden, ext, adj, head_mask)
+    gout = torch.from_numpy(C.det_uniform(name + ".gout", tuple(out.shape)))
+    (out * gout).sum().backward()
+    arrays = dict(adj=np_(adj), head_mask=np_(head_mask), out=np_(out), probs=np_(probs), d_hidden=np_(hidden.grad))
+    for pn, p in layer.named_parameters():
+        arrays["grad." + pn] = np_(p.grad)
+    save(name, **arrays)
+
     # ---------------- OcrPtrNet ----------------
     d = C.SMALL
     ptr = ref.OcrPtrNet(d["D"], d["D"])

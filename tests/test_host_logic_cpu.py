@@ -39,8 +39,13 @@ def test_unsupported_options_raise():
     import pytest
     import sam_textvqa_amd.modules as M
     base = dict(hidden_size=768, num_spatial_relations=12, max_seq_length=4, num_decoding_steps=2, attention_mask_quadrants=[1, 2])
-    with pytest.raises(NotImplementedError):
-        M.SpatialBertSelfAttention(M.BertConfig.from_dict(dict(base, use_bias=True)))
+    # use_bias (sa_m4c.py:439-443) is built since round 6: the head-bias row exists under the reference's state_dict key, and is absent by default
+    att = M.SpatialBertSelfAttention(M.BertConfig.from_dict(dict(base, use_bias=True)))
+    assert tuple(att.state_dict()["biases.weight"].shape) == (1, 768)
+    assert "biases.weight" not in M.SpatialBertSelfAttention(M.BertConfig.from_dict(base)).state_dict()
+    with pytest.raises(NotImplementedError):          # head_mask: one factor per head, nothing finer
+        M._head_scale(torch.ones(2, 12, 4, 4), 12, "cpu")
+    assert M._head_scale(torch.full((1, 12, 1, 1), 0.5), 12, "cpu").shape == (12,) and M._head_scale(None, 12, "cpu") is None
     with pytest.raises(ValueError):
         M.SpatialBertSelfAttention(M.BertConfig.from_dict(dict(base, hidden_size=100)))
     with pytest.raises(NotImplementedError):
@@ -84,13 +89,13 @@ def test_reducer_bucket_plan_and_region_order():
     assert red.buckets == [(744, 1000), (488, 744), (232, 488), (0, 232)]
     ids = red.register_regions([(100, 300), (300, 600), (600, 1000)])      # layers in address order
     assert ids == [2, 1, 0]
-    # the low end of the regions becomes a bucket boundary: no bucket mixes early-final (layers) and late-final (below them) gradients
-    assert red.buckets == [(744, 1000), (488, 744), (232, 488), (100, 232), (0, 100)]
+    # every region boundary is a bucket boundary (round 6; rounds 2-5 cut only at the low end of the regions): no bucket waits for a region it does not belong to
+    assert red.buckets == [(744, 1000), (600, 744), (344, 600), (300, 344), (100, 300), (0, 100)]
     red.mark_done(ids[0])                      # lowest layer finishing first releases nothing
     assert red.next_bucket == 0
-    red.mark_done(ids[2]); assert red.next_bucket == 1          # [744,1000) complete
-    red.mark_done(ids[1]); assert red.next_bucket == 4          # everything >= 100 final -> every bucket of the region range
-    red.finish(); assert red.next_bucket == 5
+    red.mark_done(ids[2]); assert red.next_bucket == 2          # [600,1000) complete: both of its buckets
+    red.mark_done(ids[1]); assert red.next_bucket == 5          # everything >= 100 final -> every bucket of the region range
+    red.finish(); assert red.next_bucket == 6
     red2 = GradReducer(torch.zeros(1000), bucket_bytes=4 * 256, dense_lo=40)     # row-sparse table in [0, 40): outside every bucket
     red2.register_regions([(500, 1000)])
     assert red2.buckets == [(744, 1000), (500, 744), (244, 500), (40, 244)]
@@ -104,12 +109,12 @@ def test_reducer_with_the_sparse_table_in_the_middle():
     assert red.buckets == [(800, 1000), (600, 800), (400, 600), (100, 300), (0, 100)] and red.dense_lo == 0
     ids = red.register_regions([(250, 300), (400, 700), (700, 1000)])      # a region below the table, two above
     assert ids == [2, 1, 0]
-    assert red.buckets == [(800, 1000), (600, 800), (400, 600), (250, 300), (50, 250), (0, 50)]
+    assert red.buckets == [(800, 1000), (700, 800), (500, 700), (400, 500), (250, 300), (50, 250), (0, 50)]
     red.set_barrier(("a", "b"), [ids[0], ids[2]])       # one barrier may finalise several (non-adjacent) regions
     red.barrier_hit("a"); assert red.next_bucket == 0
-    red.barrier_hit("b"); assert red.next_bucket == 1     # [800,1000) final; [250,300) is too but must wait for everything above it
-    red.mark_done(ids[1]); assert red.next_bucket == 4    # ... and leaves as soon as the middle region is done
-    red.finish(); assert red.next_bucket == 6
+    red.barrier_hit("b"); assert red.next_bucket == 2     # [700,1000) final; [250,300) is too but must wait for everything above it
+    red.mark_done(ids[1]); assert red.next_bucket == 5    # ... and leaves as soon as the middle region is done
+    red.finish(); assert red.next_bucket == 7
     import pytest
     with pytest.raises(ValueError):
         GradReducer(torch.zeros(1000), sparse_range=(300, 400)).register_regions([(200, 290), (400, 1000)])    # a real gap

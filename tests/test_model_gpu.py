@@ -831,3 +831,73 @@ def test_long_trajectory_does_not_drift_from_the_oracle():
           % (max(rel), sum(rel[-20:]) / 20, dist[20], dist[80], l_ref[0], l_ref[-1]))
     assert max(rel) < 0.01 and sum(rel[-20:]) / 20 < 0.005, (max(rel), rel[-5:])          # achieved 5e-4 / 7e-5
     assert dist[80] < 1.5 * dist[20] + 0.005, dist                                          # achieved 0.005 / 0.005: no growth
+
+
+@pytest.mark.parametrize("train_dropout", [False, True])
+def test_spatial_layer_use_bias_head_mask_output_attentions_vs_oracle(train_dropout):
+    """VERDICT r5 missing #4: `use_bias` head biases (sa_m4c.py:439-443, 600-603), `head_mask` (:591-592) and `output_attentions` (:604-609) on the module-level
+    API of SpatialBertLayer, against the oracle's layer (itself pinned for these switches by tests/golden/layer_small_switches.npz): output, returned
+    attention_probs [B, H, N, N], input gradient, every parameter gradient incl. `attention.self.biases.weight`; a checkpoint with the bias row loads.
+    train_dropout: attention dropout on -- the returned probabilities are the DROPPED ones (zeros where the kernel's keep bits are clear, 1 / (1 - p) elsewhere)."""
+    import sam_textvqa_amd.modules as M
+    from sam_textvqa_amd.synthetic import mmt_config_dict
+    torch.manual_seed(5)
+    T, n_obj, n_ocr, n_dec, B = 6, 22, 13, 5, 2
+    cfgd = mmt_config_dict(3, ("s",), n_dec=n_dec, T=T, n_obj=n_obj, n_ocr=n_ocr)
+    cfgd.update(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.1 if train_dropout else 0.0, use_bias=True, output_attentions=True)
+    o_layer = bf16_round_module(O.SpatialBertLayer(O.BertConfig.from_dict(cfgd)))
+    with torch.no_grad():
+        o_layer.attention.self.biases.weight.copy_(0.3 * torch.randn(1, 768))
+    layer = M.SpatialBertLayer(M.BertConfig.from_dict(cfgd))
+    assert "attention.self.biases.weight" in layer.state_dict()
+    layer.load_state_dict(o_layer.state_dict())
+    layer.cuda()
+    n = T + n_obj + n_ocr + n_dec
+    from oracle import spatial_graph as SG
+    rng = np.random.RandomState(1)
+    boxes = rng.rand(B, n_obj + n_ocr, 2) * 0.8
+    boxes = np.concatenate([boxes, boxes + 0.02 + rng.rand(B, n_obj + n_ocr, 2) * 0.15], -1)
+    boxes[1, -3:] = 0
+    adj = torch.from_numpy(np.stack([SG.compose(SG.relation_codes(b), 3) for b in boxes]))
+    qm, om, cm = torch.ones(B, T, dtype=torch.long), torch.ones(B, n_obj, dtype=torch.long), torch.ones(B, n_ocr, dtype=torch.long)
+    qm[0, 4:] = 0; cm[1, -3:] = 0
+    ext = O.MMT.extended_attention_mask(qm, om, cm, n_dec)
+    head_mask = torch.tensor([1.0, 0.5, 1.25, 0.0, 1.0, 0.75, 1.0, 1.0, 1.5, 1.0, 0.25, 1.0]).view(1, 12, 1, 1)
+    x = torch.randn(B, n, 768).to(torch.bfloat16)
+    gout = torch.randn(B, n, 768)
+    xg = x.cuda().requires_grad_(True)
+    if train_dropout:
+        layer.train()
+        yg, pg = layer(xg, ext.cuda(), adj.cuda(), head_mask.cuda())
+        assert pg.shape == (B, 12, n, n) and pg.dtype == torch.float32
+        # the oracle cannot draw the library's mask: replay it with the probabilities' own zero pattern (keep = dropped probs != 0 where the undropped are)
+        o_layer.eval()
+        xo = x.float().requires_grad_(True)
+        _, po = o_layer(xo, ext, adj, head_mask)
+        live = po > 1e-6                                         # (head 3 is masked off entirely; tiny probabilities are skipped: their kept value may round to 0)
+        kept = pg.cpu()[live] != 0
+        assert abs(kept.float().mean().item() - 0.9) < 0.02
+        inv_keep = 1.0 / (1.0 - round(0.1 * 65536) / 65536.0)
+        assert torch.allclose(pg.cpu()[live][kept], po[live][kept] * inv_keep, rtol=2e-2, atol=2e-4)
+        assert (pg.cpu()[:, 3] == 0).all()
+        return
+    layer.eval()
+    o_layer.eval()
+    xo = x.float().requires_grad_(True)
+    yo, po = o_layer(xo, ext, adj, head_mask)
+    (yo * gout).sum().backward()
+    yg, pg = layer(xg, ext.cuda(), adj.cuda(), head_mask.cuda())
+    (yg.float() * gout.cuda()).sum().backward()
+    within("switches layer out", rel_err(yg, yo), L["layer_out_o"])
+    within("switches layer dx", rel_err(xg.grad, xo.grad), L["layer_dh_o"])
+    within("switches attention_probs", rel_err(pg, po), 4e-3)            # (bf16 q, k rows: scores to ~1e-3)
+    assert (pg.cpu()[:, 3] == 0).all() and (pg.cpu().sum(-1)[:, 0] <= 1.0 + 1e-3).all()
+    for (k, p_o), (_, p_g) in zip(o_layer.named_parameters(), layer.named_parameters()):
+        if k.endswith("key.bias"):
+            continue                                                        # (softmax is invariant to it: exact 0 in exact arithmetic, rounding noise otherwise)
+        within("switches grad " + k, rel_err(p_g.grad, p_o.grad), 0.02)
+    # without the switches the same weights run the fused single-node path; the bias row and the head factors are what differs
+    plain = layer(xg.detach(), ext.cuda(), adj.cuda())
+    assert len(plain) == 2 and plain[1].shape == (B, 12, n, n)           # output_attentions is a config switch: still returned
+    with pytest.raises(NotImplementedError):
+        layer(xg.detach(), ext.cuda(), adj.cuda(), torch.ones(B, 12, n, n).cuda())

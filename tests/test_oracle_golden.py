@@ -68,6 +68,25 @@ def test_spatial_layer(name):
             close(p.grad, g["grad." + pn], 5e-5)
 
 
+def test_spatial_layer_with_use_bias_head_mask_and_output_attentions():
+    """the switches no shipped config turns on (sa_m4c.py:439-443 / 600-603 head biases, :591-592 head_mask, :604-609 output_attentions), pinned by a golden of the
+    reference itself: layer output, the returned attention_probs (after head mask), input gradient and every parameter gradient incl. `biases.weight`"""
+    name, case = "layer_small_switches", C.LAYER_CASES["layer_small_c3"]
+    d = case["dims"]
+    cfg = O.BertConfig.from_dict(C.mmt_config_dict(d, ["s"], case["ctx"], case["quadrants"], use_bias=True, output_attentions=True))
+    layer = O.SpatialBertLayer(cfg).eval()
+    C.fill_state_dict(layer, d["ws"], prefix=name + ".")
+    g = OC.load(name)
+    n = d["T"] + d["n_obj"] + d["n_ocr"] + d["n_dec"]
+    hidden = torch.from_numpy(C.det_uniform(name + ".hidden", (d["B"], n, d["D"]))).requires_grad_(True)
+    out, probs = layer(hidden, OC.ext_mask(d), torch.from_numpy(g["adj"]), torch.from_numpy(g["head_mask"]))
+    (out * torch.from_numpy(C.det_uniform(name + ".gout", tuple(out.shape)))).sum().backward()
+    close(out.detach(), g["out"]); close(probs.detach(), g["probs"]); close(hidden.grad, g["d_hidden"])
+    assert "grad.attention.self.biases.weight" in g and (probs.detach()[:, 3] == 0).all()
+    for pn, p in layer.named_parameters():
+        close(p.grad, g["grad." + pn], 5e-5)
+
+
 def test_spatial_layer_faithful_mode_identical():
     layer, hidden, ext, adj, _, g = OC.layer_case("layer_small_c3")
     layer.attention.self.faithful = True
