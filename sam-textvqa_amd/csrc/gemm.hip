@@ -98,7 +98,18 @@ __device__ __forceinline__ bf16x8 load_frag(const unsigned char* lds, int row0, 
 // Tile configuration: BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN).
 //   <128,128,2,2>: 256 threads, 64 KB LDS, 2 blocks/CU  -- 64 flop per byte staged
 //   <256,256,2,4>: 512 threads, 128 KB LDS, 1 block/CU  -- 128 flop per byte staged (opt-in via force_tile, see launch())
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+template <int N>
+__device__ __forceinline__ void vmwait_n() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NST = LDS stages.  2: the round-1 loop (one k-tile of lead, __syncthreads per k-tile -- the compiler drains vmcnt to 0 in front of it, so every k-tile pays
+// most of a memory latency).  3 / 4 (round 6, the 64 x 64 configuration): a ring of NST stages with NST - 1 k-tiles requested ahead, raw s_barrier and a COUNTED
+// s_waitcnt vmcnt(tiles still allowed in flight x DMA instructions per wave and tile): the launches this configuration serves are the latency chains of the step --
+// TextBert's 1280-row products (12 k-tiles at K = 768: one block per tile slot, nothing to hide a k-tile's latency behind), the heads, the split-K partials --
+// where a block's time was 12 x (latency + 0.05 us of MFMAs).  Same k order, same accumulation: bit-identical results.
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT, int NST = 2>
 __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_block) {
   constexpr int NT = 64 * WM * WN, NWAVES = WM * WN;
   constexpr int TM = BM / WM / 16, TN = BN / WN / 16;      // 16x16 fragments per wave
@@ -159,13 +170,32 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
       store_tile<BKC, BN, NT>(Bs_, rb, tid);
     }
   };
-  fill(kt_begin, 0);
+  constexpr int LPT = (BM / 8 + BN / 8) / NWAVES;          // direct-to-LDS instructions per wave and k-tile
+  const bool ring = NST > 2 && KT <= KT_full;                // (a partial last k-tile is register staged: ordinary loads + ds_writes, the simple loop handles it)
+  if (ring) {
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0)
+      if (kt_begin + s0 < KT) fill(kt_begin + s0, s0);
+  } else {
+    fill(kt_begin, 0);
+  }
+  int stage = 0;
   for (int kt = kt_begin; kt < KT; ++kt) {
-    const int stage = (kt - kt_begin) & 1;
-    __syncthreads();   // tile kt has landed (the compiler drains vmcnt before the barrier) and everyone left stage^1
-    if (kt + 1 < KT) fill(kt + 1, stage ^ 1);
+    if (ring) {
+      // k-tiles kt .. min(kt + NST - 2, KT - 1) are out; this wave's pieces of k-tile kt have landed once no more than (tiles behind it) x LPT loads are pending
+      const int ahead = min(NST - 2, KT - 1 - kt);
+      if (ahead >= 2) vmwait_n<(NST > 3 ? 2 : 0) * LPT>();      // (rings deeper than three: measured slower -- fewer resident blocks -- and not instantiated)
+      else if (ahead == 1) vmwait_n<LPT>();
+      else vmwait_n<0>();
+      __builtin_amdgcn_s_barrier();          // everyone's pieces of k-tile kt are in LDS, and everyone has consumed the fragments of k-tile kt - 1
+      if (kt + NST - 1 < KT) fill(kt + NST - 1, stage == 0 ? NST - 1 : stage - 1);      // into the stage k-tile kt - 1 was read from
+    } else {
+      __syncthreads();   // tile kt has landed (the compiler drains vmcnt before the barrier) and everyone left stage^1
+      if (kt + 1 < KT) fill(kt + 1, stage ^ 1);
+    }
     const unsigned char* As = smem + stage * STAGE_BYTES;
     const unsigned char* Bs = As + A_BYTES;
+    stage = ring ? (stage + 1 == NST ? 0 : stage + 1) : stage ^ 1;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[TM], bf[TN];
@@ -200,9 +230,9 @@ __device__ __forceinline__ void gemm_block(const GemmArgs& p, const int linear_b
   gemm_epilogue<TM, TN, EPI, OutT>(p, acc, m0 + wm * (BM / WM), n0 + wn * (BN / WN), m0 + BM <= p.M && n0 + BN <= p.N, Cout, ldc, accumulate, i, g);
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT, int NST = 2>
 __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_kernel(GemmArgs p) {   // 2 waves per SIMD = two 4-wave blocks (or one 8-wave block) per CU
-  gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT>(p, blockIdx.x);
+  gemm_block<BM, BN, WM, WN, AKC, BKC, EPI, OutT, NST>(p, blockIdx.x);
 }
 
 // Grouped launch: up to 12 independent problems of the same kind in ONE grid (block ranges start at multiples of 8 so the XCD-aware
@@ -408,15 +438,15 @@ __global__ __launch_bounds__(256) void splitk_epilogue_ln_kernel(const float* ws
   if (lane == 0) { ln.mean[row] = mean; ln.rstd[row] = rstd; }
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT>
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, int EPI, typename OutT, int NST = 2>
 int launch_cfg(GemmArgs a, hipStream_t st) {
-  constexpr size_t LDS = (size_t)2 * (BM + BN) * BK * 2;
+  constexpr size_t LDS = (size_t)NST * (BM + BN) * BK * 2;
   static bool once = false;
   if (!once) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS);
     once = true;
   }
-  gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(64 * WM * WN), LDS, st>>>(a);
+  gemm_kernel<BM, BN, WM, WN, AKC, BKC, EPI, OutT, NST><<<dim3(a.tiles_m * a.tiles_n * a.split_k), dim3(64 * WM * WN), LDS, st>>>(a);
   if (a.split_used) *a.split_used = a.split_k;
   if (a.split_k > 1 && !a.defer_reduce) {
     const int64_t mn4 = (int64_t)a.M * a.N / 4;
@@ -487,7 +517,15 @@ int launch(GemmArgs a, hipStream_t st, int want_split, int64_t ws_bytes, int for
   // >= 4 blocks per CU) quadruple the grid.  Used when the 128x128 grid would not even fill half of the 512 block slots.
   if (force_tile == 64 || (force_tile == 0 && want_split == 0 && (int64_t)((a.M + 127) / 128) * tn < 256)) {
     a.tiles_m = (a.M + 63) / 64; a.tiles_n = (a.N + 63) / 64;
-    if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, 4, per_split, ws_bytes);
+    // LDS stages of the 64 x 64 configuration (16 KB each).  2 (default): the round-1 loop.  SAM_GEMM64_STAGES=3: a ring of three with two k-tiles requested ahead
+    // and counted vmcnt waits (gemm_block<..., NST>) -- built in round 6 on the theory that TextBert's 1280-row products are chains of exposed k-tile latencies,
+    // measured, and NOT faster (profiles/r6_gemm_experiments.txt: QKV 13.5 -> 13.3 us, O-projection 9.2 -> 8.7, four stages 16.5 / 9.1 at two blocks per CU;
+    // only the unsplit K = 3072 product gains, 26.8 -> 20.5, which the split-K form already beats): 720 tiles of 64 x 64 re-fetch A 36 and B 20 times --
+    // 138 MB of L2 -> LDS traffic for a 4.5 GFLOP product -- and that stream, not its latency, is what a launch waits for.  Bit-identical results either way.
+    static int nst = -1;
+    if (nst < 0) { const char* e = getenv("SAM_GEMM64_STAGES"); nst = e ? atoi(e) : 2; if (nst != 3) nst = 2; }
+    if (want_split != 0) a.split_k = pick_split(want_split, a.tiles_m * a.tiles_n, kt, nst == 2 ? 4 : 3, per_split, ws_bytes);
+    if (nst == 3) return launch_cfg<64, 64, 2, 2, AKC, BKC, EPI, OutT, 3>(a, st);
     return launch_cfg<64, 64, 2, 2, AKC, BKC, EPI, OutT>(a, st);
   }
   int bm = 128;

@@ -145,15 +145,15 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
     import socket
     import subprocess
     import sys
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAM_FORCE_DIST="1", SAM_REDUCER_CHECK="1", SAM_GRAD_PAYLOAD=payload, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
-        env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline"]
-    from tests.util import run_child
-    r = run_child(cmd, env, None, "bench_dist_run_one_rank_%s" % payload, timeout=900)
+
+    def make(port):
+        env = dict(os.environ, SAM_FORCE_DIST="1", SAM_REDUCER_CHECK="1", SAM_GRAD_PAYLOAD=payload, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline", "--no-eager-baseline", "--no-roofline", "--no-secondary"], env
+    r = _run_child_with_fresh_port(make, None, "bench_dist_run_one_rank_%s" % payload, timeout=900)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
@@ -171,15 +171,15 @@ def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
     import json
     import subprocess
     import sys
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1", SAM_BENCH_EAGER_COMM_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAM_DP_CU_RESERVE="32")
-    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAM_FORCE_DIST", "SAM_REDUCER_CHECK"):
-        env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"]
-    from tests.util import run_child
-    r = run_child(cmd, env, None, "bench_dist_run_two_ranks", timeout=300)
+
+    def make(port):
+        env = dict(os.environ, SAM_DIST_BACKEND="gloo", SAM_DIST_SHARE_GPU="1", SAM_BENCH_EAGER_COMM_LEG="1", HSA_ENABLE_IPC_MODE_LEGACY="0", SAM_DP_CU_RESERVE="32")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "SAM_FORCE_DIST", "SAM_REDUCER_CHECK"):
+            env.pop(k, None)
+        return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2"], env
+    r = _run_child_with_fresh_port(make, None, "bench_dist_run_two_ranks", timeout=300)
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines                      # rank 0 prints, rank 1 does not
     out = json.loads(lines[0])
@@ -231,15 +231,32 @@ print("GRAPH_DP_OK")
 """
 
 
+def _run_child_with_fresh_port(make_cmd_env, marker, name, timeout=600, tries=3):
+    """run_child with a rendezvous port taken from the OS; a port can be handed out twice in a row while a previous test's agent is still closing its sockets
+    (EADDRINUSE at TCPStore creation, seen once in round 6): such a start-up failure is retried on another port, anything else fails as usual"""
+    from tests.util import run_child
+    last = None
+    for _ in range(tries):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd, env = make_cmd_env(port)
+        try:
+            return run_child(cmd, env, marker, name, timeout=timeout)
+        except AssertionError as e:
+            last = e
+            if "EADDRINUSE" not in str(e) and "address already in use" not in str(e):
+                raise
+    raise last
+
+
 def test_data_parallel_step_is_captured_and_trains_like_the_plain_step():
     """ONE step for every N: with RCCL collectives the data-parallel step (count all-reduce, bucket all-reduces forked onto the reducer stream at
     their finality marks, row-sparse table exchange, join, clip, Adam) is captured into the same kind of hipGraph as the single-GPU step and
     replayed; it trains like the eager data-parallel step and like the plain captured step (1-rank group: the sums are identities)"""
-    import subprocess
     import sys
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    env.pop("SAM_REDUCER_CHECK", None)
-    from tests.util import run_child
-    run_child([sys.executable, "-c", _GRAPH_DP_SCRIPT], env, "GRAPH_DP_OK", "graph_dp_step")
+
+    def make(port):
+        env = dict(os.environ, SAM_REPO=root, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.pop("SAM_REDUCER_CHECK", None)
+        return [sys.executable, "-c", _GRAPH_DP_SCRIPT], env
+    _run_child_with_fresh_port(make, "GRAPH_DP_OK", "graph_dp_step")

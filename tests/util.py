@@ -17,8 +17,11 @@ def unpack_bits(words, n):
 
 
 def assert_close_bf16(got, ref, frac=1e-3, ulps=1, name=""):
-    got = got.detach().float().cpu().double()
-    ref = ref.detach().float().cpu().double()
+    # the comparison itself runs where `got` lives (fp64 on the device for device tensors: the element-wise passes over 10 M-element outputs on the host were
+    # most of the GPU suite's wall time); the REFERENCE values are whatever the caller computed, on the host
+    dev = got.device
+    got = got.detach().to(torch.float64)
+    ref = ref.detach().to(device=dev, dtype=torch.float64)
     assert got.shape == ref.shape, (name, got.shape, ref.shape)
     assert torch.isfinite(got).all(), "%s: non-finite values" % name
     bound = frac * ref.abs().max() + ulps * (2.0 ** -8) * ref.abs()
