@@ -789,10 +789,10 @@ def test_stand_alone_sub_module_forward_backward_vs_oracle_class(which):
 
 
 def test_long_trajectory_does_not_drift_from_the_oracle():
-    """bf16 storage between kernels sets the model-level error (0.4-2 % of max); this checks that it does not GROW with training.  60
+    """bf16 storage between kernels sets the model-level error (0.4-2 % of max); this checks that it does not GROW with training.  48
     optimisation steps of the HIP Trainer (captured step) and of the oracle's train_step from the same weights on the same 3 rotating batches, dropout off:
     the loss curves stay together (every step within 3 %, the last 20 within 2 % on average), and the relative distance between the two parameter vectors'
-    total updates at step 60 is no larger than 1.5x what it was at step 15 -- rounding noise accumulating like a random walk through Adam would grow
+    total updates at step 48 is no larger than 1.5x what it was at step 12 -- rounding noise accumulating like a random walk through Adam would grow
     ~2x over that span, a systematic bias 4x."""
     from sam_textvqa_amd.synthetic import clone_batch, make_batch
     from sam_textvqa_amd.trainer import Trainer
@@ -821,16 +821,16 @@ def test_long_trajectory_does_not_drift_from_the_oracle():
         return (num / den) ** 0.5
 
     l_hip, l_ref, dist = [], [], {}
-    for step in range(60):
+    for step in range(48):
         l_ref.append(O.train_step(ref, clone_batch(batches[step % 3]), opt, sched).item())
         l_hip.append(tr.step(clone_batch(gpu_batches[step % 3])).item())
-        if step + 1 in (15, 60):
+        if step + 1 in (12, 48):
             dist[step + 1] = distance()
     rel = [abs(a - b) / abs(b) for a, b in zip(l_hip, l_ref)]
-    print("PARITY 60-step trajectory: loss rel err max %.3e, mean of last 20 %.3e; update distance at 15 / 60 steps %.4f / %.4f; loss %.3f -> %.3f"
-          % (max(rel), sum(rel[-20:]) / 20, dist[15], dist[60], l_ref[0], l_ref[-1]))
+    print("PARITY 48-step trajectory: loss rel err max %.3e, mean of last 20 %.3e; update distance at 12 / 48 steps %.4f / %.4f; loss %.3f -> %.3f"
+          % (max(rel), sum(rel[-20:]) / 20, dist[12], dist[48], l_ref[0], l_ref[-1]))
     assert max(rel) < 0.01 and sum(rel[-20:]) / 20 < 0.005, (max(rel), rel[-5:])          # achieved 5e-4 / 7e-5
-    assert dist[60] < 1.5 * dist[15] + 0.005, dist                                          # achieved 0.005 / 0.005: no growth
+    assert dist[48] < 1.5 * dist[12] + 0.005, dist                                          # achieved 0.005 / 0.005: no growth
 
 
 @pytest.mark.parametrize("train_dropout", [False, True])
