@@ -167,7 +167,8 @@ def test_attention_fwd_bwd(shape, spatial, p_drop):
     if p_drop > 0:
         keep = unpack_bits(keep_bits, N)
         frac = keep[allow].float().mean().item()
-        assert abs(frac - (1 - p_drop)) < 0.01, frac
+        n_allowed = int(allow.sum())            # (tools/fuzz_attention.py calls this with 30-token problems: ~1000 allowed scores, one sigma 0.0145 at p = 0.3)
+        assert abs(frac - (1 - p_drop)) < max(0.01, 4.0 * math.sqrt(p_drop * (1 - p_drop) / max(n_allowed, 1))), (frac, n_allowed)
         inv_keep = 1.0 / (1.0 - round(p_drop * 65536) / 65536.0)
     qkv_ref = qkv.float().requires_grad_(True)
     ref_out, ref_lse = oracle_attention(qkv_ref, allow, B, H, scale, keep, inv_keep)
