@@ -142,7 +142,15 @@ typedef struct sam_ln_fuse {
   void* y; int64_t ldy;          /* bf16 [M, N] */
   float* mean; float* rstd;      /* fp32 [M] */
   int32_t done;                  /* OUT */
+  /* Round 6 -- the LayerNorm INSIDE an MMT-size launch (SURVEY 8(b) linear_bias_dropout_residual_ln as one kernel; sa_m4c.py:653, 680): with a workspace of
+   * sam_gemm_ln_ws_bytes(M, N) bytes here (ZERO-FILLED once by the caller, private to one stream; every launch leaves its counters zero again; word 0 is an error
+   * word raised when a bounded wait ran out) a product that the loader-wave kernel covers in ONE round of tiles normalises its rows itself: the waves / blocks that
+   * share a row exchange (mean, M2) pairs through the workspace.  y / mean / rstd then equal sam_layernorm_fwd(C) up to fp32 rounding of the statistics
+   * (the split-K form above is bit-identical).  NULL: never.  OPT-IN (SAM_GEMM_LN_FUSE=1): correct, and measured 2.4x slower than sam_gemm_bf16 + sam_layernorm_fwd
+   * (a row's statistics cross XCDs: memory-side round trips on an otherwise idle CU -- profiles/r6_gemm_experiments.txt #16). */
+  float* xws; int64_t xws_bytes;
 } sam_ln_fuse;
+int64_t sam_gemm_ln_ws_bytes(int M, int N);
 typedef struct sam_gemm_desc {
   int32_t M, N, K;
   int32_t a_kcontig, b_kcontig;

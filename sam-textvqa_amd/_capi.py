@@ -12,7 +12,8 @@ _vp, _i, _i64, _u64, _f, _u = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_fl
 
 class LnFuse(C.Structure):
     """mirror of `sam_ln_fuse` (include/sam_hip.h)"""
-    _fields_ = [("gamma", _vp), ("beta", _vp), ("eps", _f), ("y", _vp), ("ldy", _i64), ("mean", _vp), ("rstd", _vp), ("done", C.c_int32)]
+    _fields_ = [("gamma", _vp), ("beta", _vp), ("eps", _f), ("y", _vp), ("ldy", _i64), ("mean", _vp), ("rstd", _vp), ("done", C.c_int32),
+                ("xws", _vp), ("xws_bytes", _i64)]
 
 
 class GemmDesc(C.Structure):
@@ -90,14 +91,15 @@ SIGNATURES = {
     "sam_copy_blocks": [C.c_void_p, _i, _vp],
     "sam_ge_u8": [_vp, _i64, _i64, _vp, _vp],
     "sam_greedy_decode_steps": [C.c_void_p, _vp, _i64, _vp],
+    "sam_gemm_ln_ws_bytes": [_i, _i],
     "sam_attn_probs": [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp],
     "sam_rowvec_bf16": [_i, _vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i, _vp],
     "sam_set_cu_reserve": [_i],
     "sam_get_cu_reserve": [],
     "sam_debug_cu_hog": [_i, C.c_double, _vp],
 }
-NO_STATUS = {"sam_set_rng_state", "sam_get_cu_reserve", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_attn_bwd_fused_max_n", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
-RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
+NO_STATUS = {"sam_set_rng_state", "sam_get_cu_reserve", "sam_gemm_ln_ws_bytes", "sam_layernorm_bwd_partial_rows", "sam_gemm_grouped_ws_bytes", "sam_attn_words_per_row", "sam_attn_bwd_fused_max_n", "sam_abi_version", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
+RET_I64 = {"sam_gemm_grouped_ws_bytes", "sam_gemm_ln_ws_bytes", "sam_layernorm_bwd_ws_bytes", "sam_colsum_ws_bytes", "sam_sumsq_ws_bytes", "sam_embed_sum_bwd_ws_bytes", "sam_input_encoder_bwd_ws_bytes", "sam_greedy_decode_ws_bytes", "sam_beam_step_ws_bytes"}
 
 _lib = None
 

@@ -646,6 +646,8 @@ extern "C" int64_t sam_gemm_grouped_ws_bytes(const sam_gemm_desc* descs, int cou
   return a > b ? a : b;
 }
 
+extern "C" int64_t sam_gemm_ln_ws_bytes(int M, int N) { return (M > 0 && N > 0) ? gemm_ln_ws_bytes(M, N) : 0; }
+
 extern "C" int sam_gemm_splitk_reduce(const float* ws, int split_k, int M, int N, float* C, int64_t ldc, float* bias_grad, void* stream) {
   SAM_REQUIRE(ws && C && split_k >= 1 && M > 0 && N > 0 && N % 4 == 0 && ldc % 4 == 0, "sam_gemm_splitk_reduce: bad arguments");
   const int64_t mn4 = (int64_t)M * N / 4;
@@ -754,6 +756,22 @@ extern "C" int sam_gemm_bf16(const sam_gemm_desc* d, void* stream) {
     const int64_t per_split = ((int64_t)d->M * d->N + d->M) * (int64_t)sizeof(float);
     SAM_REQUIRE(want_split < 0 || (int64_t)want_split * per_split <= d->ws_bytes || want_split > (d->K + BK - 1) / BK,
                 "sam_gemm_bf16: workspace too small for split_k=%d (%lld bytes)", d->split_k, (long long)d->ws_bytes);
+  }
+  if (d->ln && d->ln->xws && want_split == 0 && d->epilogue == SAM_EPI_BIAS_DROPOUT_RES && !d->c_is_f32 && d->a_kcontig && d->N % 16 == 0 &&
+      d->ln->xws_bytes >= gemm_ln_ws_bytes(d->M, d->N) && ((uintptr_t)d->ln->xws % 16) == 0) {
+    // LayerNorm inside the launch (gemm12.hip): offered to the launch; the launcher keeps it only for a single-round loader-wave launch and reports through `done`
+    // OFF by default: built, parity-tested (tests/test_gemm_gpu.py::test_layernorm_inside_the_mmt_size_launch) and measured SLOWER than the two launches it replaces
+    // -- O-projection 22.3 + 10.3 us as two launches, 72.7 us as one; 41 us with the waiting switched off (profiles/r6_gemm_experiments.txt #16): the rows'
+    // statistics cross XCDs, i.e. four dependent memory-side round trips (store, count in, poll, load) of ~2 us each on a CU that has nothing else to run, and
+    // 1952 waves issuing them at the same moment.  SAM_GEMM_LN_FUSE=1 selects it (read per call: the tests switch it).
+    const char* e = getenv("SAM_GEMM_LN_FUSE");
+    const int lnx = e ? atoi(e) : 0;
+    const sam_ln_fuse* l = d->ln;
+    if (lnx) {
+      SAM_REQUIRE(l->gamma && l->beta && l->y && l->mean && l->rstd && l->ldy >= d->N && l->ldy % 4 == 0, "sam_gemm_bf16: incomplete sam_ln_fuse");
+      a.ln_gamma = l->gamma; a.ln_beta = l->beta; a.ln_eps = l->eps; a.ln_y = (bf16_t*)l->y; a.ln_ldy = l->ldy; a.ln_mean = l->mean; a.ln_rstd = l->rstd;
+      a.ln_ws = l->xws; a.ln_done = const_cast<int32_t*>(&l->done);
+    }
   }
   const int64_t wsb = d->ws_bytes;
   const int ft = d->force_tile;

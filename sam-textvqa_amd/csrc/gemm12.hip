@@ -260,6 +260,15 @@ __global__ __launch_bounds__(768, 3) void gemm12_kernel(GemmArgs p) {
       }
     }
   }
+  if constexpr (EPI == SAM_EPI_BIAS_DROPOUT_RES && std::is_same<OutT, bf16_t>::value && AKC) {
+    // LayerNorm inside the launch (gemm_common.h: gemm_ln_pass): single-round launches only (launch12 checks), so the block's one tile is behind it.  BEHIND the
+    // k-loop on purpose: inside it the pass's 60-odd registers were live next to the loop's and the 192 x 192 kernels spilled 200-400 bytes per lane
+    if (p.ln_y) {
+      int lm0, ln0;
+      tile_origin12<BM, BN>(p, blockIdx.x, lm0, ln0);
+      gemm_ln_pass<BM, BN>(p, lm0, ln0, wr, wc, lane);
+    }
+  }
 }
 
 template <int BM, int BN, bool AKC, bool BKC, int EPI, typename OutT, int NST, int PH = 2>
@@ -273,8 +282,13 @@ int launch12(GemmArgs a, int n_cu, hipStream_t st) {
   }
   a.tiles_m = (a.M + BM - 1) / BM; a.tiles_n = (a.N + BN - 1) / BN;
   const int tiles = a.tiles_m * a.tiles_n;
+  // LayerNorm inside the launch: every tile resident at once (its waves wait for each other), whole column tiles, the workspace's counter range, 32-bit byte offsets
+  if (a.ln_y && !(EPI == SAM_EPI_BIAS_DROPOUT_RES && std::is_same<OutT, bf16_t>::value && AKC && tiles <= n_cu && a.N % BN == 0 && a.tiles_n <= 4 && a.tiles_m <= 1024 &&
+                  (int64_t)a.M * a.ldc * 2 < (int64_t)0x7fffffff && (int64_t)a.M * 4 * a.tiles_n * 8 < (int64_t)0x7fffffff))
+    a.ln_y = nullptr;
   gemm12_kernel<BM, BN, AKC, BKC, EPI, OutT, NST, PH><<<dim3(tiles < n_cu ? tiles : n_cu), dim3(768), LDS, st>>>(a);
   SAM_LAUNCH_CHECK();
+  if (a.ln_y && a.ln_done) *a.ln_done = 1;
   return SAM_OK;
 }
 
@@ -305,7 +319,7 @@ int pick12(const GemmArgs& a, int tile, hipStream_t st) {
 // SAM_ERR_UNSUPPORTED (error string untouched) when the problem has no instance here: the caller goes on to the 8-wave kernels
 int samgemm::gemm12_launch(const GemmArgs& a_in, int lay, int e, int c_is_f32, int tile, hipStream_t st) {
   GemmArgs a = a_in;
-  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("SAM_GEMM8_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg & 1; }
+  { static int dbg = -1; if (dbg < 0) { const char* v = getenv("SAM_GEMM8_DBG"); dbg = v ? atoi(v) : 0; } a.dbg = dbg & (1 | 8 | 16 | 32); }
   if (lay == 0 && c_is_f32 && e == SAM_EPI_NONE && tile == 12448 && a.K % BK == 0 && a.bias_grad == nullptr && a.M % 8 == 0) {
     // (experiment: the weight-gradient layout -- both operands k-strided, fp32 accumulate -- on the loader-wave core, one problem; profiles/r5_gemm_experiments.txt)
     if ((int64_t)a.K * a.lda * 2 >= (int64_t)0x7fffffff || (int64_t)a.K * a.ldb * 2 >= (int64_t)0x7fffffff) return SAM_ERR_UNSUPPORTED;

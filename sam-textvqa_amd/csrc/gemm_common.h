@@ -31,6 +31,11 @@ struct GemmArgs {
   int defer_reduce;   // split-K: leave the partials in ws, the caller runs sam_gemm_splitk_reduce itself
   int* split_used;    // host pointer: receives the split factor actually launched
   int stagger;        // gemm4 kernels: start delay of the second block slot of every CU, in units of ~3.7 us (s_sleep 127)
+  // LayerNorm inside the launch (gemm12.hip, round 6): ln_y != NULL = after its epilogue every compute wave normalises the rows of its own sub-tile; the row
+  // statistics are exchanged between the waves / blocks that share a row through ln_ws (gemm_ln_pass below).  Host-side: *ln_done = 1 when the launch did it.
+  const float* ln_gamma; const float* ln_beta; float ln_eps;
+  bf16_t* ln_y; int64_t ln_ldy; float* ln_mean; float* ln_rstd;
+  float* ln_ws; int* ln_done;
   int dbg;            // tuning experiments only (SAM_GEMM8_DBG; results are garbage): 1 = gemm8 kernels skip the epilogue, 2 = every tile's epilogue
                       // lands on the first tile row (outputs / residual / auxiliary rows stay in the L2: the epilogue without its HBM traffic)
 };
@@ -290,6 +295,137 @@ __device__ __forceinline__ void gemm_epilogue8(const GemmArgs& p, const f32x4 (&
   if (full) gemm_epilogue8_impl<TM, TN, EPI, OutT, true, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
   else gemm_epilogue8_impl<TM, TN, EPI, OutT, false, T0, T1>(p, acc, mw, nw, Cout, ldc, accumulate, i, g);
 }
+
+// ---- LayerNorm inside an MMT-size GEMM launch (linear_bias_dropout_residual_ln as ONE kernel; sa_m4c.py:653, 680, 1016-1028) -------------------------
+// The launch is ONE round of tiles (tiles <= blocks, every block resident) of BM x BN with N a multiple of BN: a row of the output is spread over tiles_n blocks x 4
+// waves.  After the epilogue has stored z = bf16(dropout(x W^T + b) + residual) -- what the backward reads -- every compute wave
+//   1. re-reads ITS OWN (BM/2) x (BN/4) sub-tile of z (it wrote it: one s_waitcnt away, L2-resident), 4 lanes per row;
+//   2. reduces each row's BN/4 values to (mean_i, M2_i) -- two passes, in registers -- and publishes the pair (agent-scope store) in ln_ws[row][part];
+//   3. counts itself in on the (row block, row half) counter and waits for the P = 4 tiles_n parts of its rows (bounded spin: see gemm8w.hip);
+//   4. merges the P pairs in a fixed order (equal counts: mean = avg(mean_i), M2 = sum M2_i + n sum (mean_i - mean)^2), normalises the values it still holds and
+//      stores y; part 0 also stores mean / rstd; the last wave to leave a counter resets it (the next launch finds zeros again).
+// No block-wide barrier (the loader waves of gemm12_kernel have returned by then), no atomics on data, bit-reproducible.  The statistics differ from the
+// stand-alone kernel's (one 768-term sum per row) by fp32 rounding only; y within one bf16 ulp (tests/test_gemm_gpu.py).
+// Workspace layout (floats): [0] error word | [64 ..) counters: (arrive, depart) per (tile_m, half) | [LN_WS_PART0 ..) pairs [row][part].
+constexpr int LN_WS_COUNTERS = 64, LN_WS_PART0 = 64 + 4 * 1024;          // up to 1024 row tiles
+constexpr int AUX_SC1_LN = 0x10;
+
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_ln_pass(const GemmArgs& p, int m0, int n0, int wr, int wc, int lane) {
+  constexpr int RW = BM / 2, CW = BN / 4, TR = RW / 16, NPC = CW / 16;         // rows / columns per wave, 16-row groups, 16-column pieces (4 columns per lane each)
+  const int r16 = lane >> 2, q = lane & 3;
+  const int tile_m = m0 / BM, tile_n = n0 / BN, P = 4 * p.tiles_n, part = 4 * tile_n + wc;
+  const bf16_t* z = reinterpret_cast<const bf16_t*>(p.C);
+  if (p.dbg & 32) return;                                                         // (tuning: the launch with the pass switched off inside the kernel)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                               // this wave's epilogue stores have reached the L2
+  typedef unsigned lnvu2 __attribute__((ext_vector_type(2)));
+  const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)z, 0, 0x7fffffff, 0x00020000);
+  uint2 zr[TR][NPC];
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    const int row = min(m0 + wr * RW + 16 * t + r16, p.M - 1);
+#pragma unroll
+    for (int c = 0; c < NPC; ++c) {
+      const lnvu2 u = __builtin_amdgcn_raw_buffer_load_b64(rz, (unsigned)(((int64_t)row * p.ldc + n0 + wc * CW + 16 * c + 4 * q) * 2), 0, 0);
+      zr[t][c] = make_uint2(u[0], u[1]);
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ln_ws + LN_WS_PART0), 0, 0x7fffffff, 0x00020000);
+  // ---- 2. this wave's part of every row
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < NPC; ++c) s += (bf_lo(zr[t][c].x) + bf_hi(zr[t][c].x)) + (bf_lo(zr[t][c].y) + bf_hi(zr[t][c].y));
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    const float mi = s * (1.0f / CW);
+    float m2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < NPC; ++c) {
+      const float d0 = bf_lo(zr[t][c].x) - mi, d1 = bf_hi(zr[t][c].x) - mi, d2 = bf_lo(zr[t][c].y) - mi, d3 = bf_hi(zr[t][c].y) - mi;
+      m2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+    }
+    m2 += __shfl_xor(m2, 1);
+    m2 += __shfl_xor(m2, 2);
+    const int row = m0 + wr * RW + 16 * t + r16;
+    if (q == 0 && row < p.M) {
+      const lnvu2 pr = {__float_as_uint(mi), __float_as_uint(m2)};
+      __builtin_amdgcn_raw_buffer_store_b64(pr, rs, (unsigned)(((int64_t)row * P + part) * 8), 0, AUX_SC1_LN);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  // ---- 3. count in, wait for the other parts of these rows
+  unsigned* cnt = reinterpret_cast<unsigned*>(p.ln_ws) + LN_WS_COUNTERS + 2 * (2 * tile_m + wr);
+  if (lane == 0 && !(p.dbg & 16)) {
+    __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned spins = 0;
+    while (!(p.dbg & 8) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)P) {
+      __builtin_amdgcn_s_sleep(4);
+      if (++spins > (1u << 21)) { __hip_atomic_store(reinterpret_cast<unsigned*>(p.ln_ws), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }      // a part never arrived: error word, garbage out, no hang
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  asm volatile("" ::: "memory");
+  // ---- 4. merge, normalise, store
+  float g4[NPC][4], b4[NPC][4];
+#pragma unroll
+  for (int c = 0; c < NPC; ++c) {
+    const float4 gv = *reinterpret_cast<const float4*>(p.ln_gamma + n0 + wc * CW + 16 * c + 4 * q), bv = *reinterpret_cast<const float4*>(p.ln_beta + n0 + wc * CW + 16 * c + 4 * q);
+    g4[c][0] = gv.x; g4[c][1] = gv.y; g4[c][2] = gv.z; g4[c][3] = gv.w;
+    b4[c][0] = bv.x; b4[c][1] = bv.y; b4[c][2] = bv.z; b4[c][3] = bv.w;
+  }
+  bf16_t* y = p.ln_y;
+  // every pair this lane needs is requested BEFORE the first is used (lane q takes parts q, q + 4, ...; P / 4 = tiles_n <= 4 of them per row, at a clamped index
+  // with weight 0 past P): agent-scope loads come from the memory side at 1-2 us each, and the first version of this loop -- one dependent pair of loads per
+  // trip, 24 trips per lane -- cost 36 us per launch
+  lnvu2 pp[TR][4];
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    const int rc = min(m0 + wr * RW + 16 * t + r16, p.M - 1);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      pp[t][u] = __builtin_amdgcn_raw_buffer_load_b64(rs, (unsigned)(((int64_t)rc * P + min(q + 4 * u, P - 1)) * 8), 0, AUX_SC1_LN);
+  }
+#pragma unroll
+  for (int t = 0; t < TR; ++t) {
+    const int row = m0 + wr * RW + 16 * t + r16;
+    float s1 = 0.f, s2 = 0.f, sm = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float wgt = (q + 4 * u < P) ? 1.f : 0.f;
+      const float mi = __uint_as_float(pp[t][u][0]) * wgt, m2 = __uint_as_float(pp[t][u][1]) * wgt;
+      s1 += mi; s2 += mi * mi; sm += m2;
+    }
+    s1 += __shfl_xor(s1, 1); s1 += __shfl_xor(s1, 2);
+    s2 += __shfl_xor(s2, 1); s2 += __shfl_xor(s2, 2);
+    sm += __shfl_xor(sm, 1); sm += __shfl_xor(sm, 2);
+    const float mean = s1 / (float)P;
+    const float m2_all = sm + (float)CW * fmaxf(s2 - (float)P * mean * mean, 0.f);
+    const float rstd = 1.0f / sqrtf(m2_all / (float)p.N + p.ln_eps);
+    if (row < p.M) {
+#pragma unroll
+      for (int c = 0; c < NPC; ++c) {
+        const float v0 = bf_lo(zr[t][c].x), v1 = bf_hi(zr[t][c].x), v2 = bf_lo(zr[t][c].y), v3 = bf_hi(zr[t][c].y);
+        uint2 o;
+        o.x = pack_bf16x2(g4[c][0] * ((v0 - mean) * rstd) + b4[c][0], g4[c][1] * ((v1 - mean) * rstd) + b4[c][1]);
+        o.y = pack_bf16x2(g4[c][2] * ((v2 - mean) * rstd) + b4[c][2], g4[c][3] * ((v3 - mean) * rstd) + b4[c][3]);
+        *reinterpret_cast<uint2*>(y + (int64_t)row * p.ln_ldy + n0 + wc * CW + 16 * c + 4 * q) = o;
+      }
+      if (part == 0 && q == 0) { p.ln_mean[row] = mean; p.ln_rstd[row] = rstd; }
+    }
+  }
+  // ---- leave: the last of the P waves puts the counters back to zero
+  if (lane == 0 && !(p.dbg & 16)) {
+    const unsigned left = __hip_atomic_fetch_add(cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (left == (unsigned)P - 1) {
+      __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// workspace bytes of the in-launch LayerNorm for an M x N output (16 parts per row cover N <= 768 at 192-wide tiles; P = 4 * ceil(N / 192) in general)
+inline int64_t gemm_ln_ws_bytes(int M, int N) { return ((int64_t)LN_WS_PART0 + (int64_t)M * (4 * ((N + 191) / 192)) * 2) * 4 + 256; }
 
 constexpr int SAM_MAX_GROUP = 12;        // problems per grouped weight-gradient launch of the 4-wave kernel (an encoder layer has 4; TextBert's three layers go out together)
 constexpr int SAM_MAX_GROUP8 = 20;       // ... of the 8-wave kernel (gemm8w.hip): an MMT pair (8) + TextBert's three layers (12) in one launch

@@ -14,7 +14,7 @@ extern "C" void sam_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* sam_last_error(void) { return g_err; }
-extern "C" int sam_abi_version(void) { return 8; }    // 8: sam_set_cu_reserve / sam_get_cu_reserve (CUs withheld from persistent grids), sam_debug_cu_hog; 7: sam_adam_step_range (the update in pieces, gated); 6: sam_attn_fwd_train / sam_attn_bwd_fused (one-pass attention backward); 5: sam_greedy_decode_steps (sam_decode_desc); 4: row-sparse regions (sam_sparse_rows) in sam_sumsq_f32 / sam_adam_step[_dev], `touched` flags in sam_embedding_bwd[_sorted]
+extern "C" int sam_abi_version(void) { return 9; }    // 9: sam_ln_fuse.xws / xws_bytes + sam_gemm_ln_ws_bytes (LayerNorm inside an MMT-size GEMM launch); 8: sam_set_cu_reserve / sam_get_cu_reserve (CUs withheld from persistent grids), sam_debug_cu_hog; 7: sam_adam_step_range (the update in pieces, gated); 6: sam_attn_fwd_train / sam_attn_bwd_fused (one-pass attention backward); 5: sam_greedy_decode_steps (sam_decode_desc); 4: row-sparse regions (sam_sparse_rows) in sam_sumsq_f32 / sam_adam_step[_dev], `touched` flags in sam_embedding_bwd[_sorted]
                                                       // 3: sam_step_advance; the grouped-wgrad workspace starts with an error word (layout changed)
                                                       // 2: sam_bce_loss takes global_count; sam_embedding_bwd_sorted; sam_build_digest; sam_gemm_desc.force_tile 1192/1256
 #ifndef SAM_BUILD_DIGEST

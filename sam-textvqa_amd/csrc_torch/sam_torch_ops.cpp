@@ -93,7 +93,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor> gemm_ln(const Tensor& a, const Tensor
     return {z, y, mean, rstd};
   }
   Tensor y = at::empty({M, N}, a.options()), mean = at::empty({M}, a.options().dtype(at::kFloat)), rstd = at::empty({M}, a.options().dtype(at::kFloat));
-  sam_ln_fuse ln = {(const float*)gamma.data_ptr(), (const float*)beta.data_ptr(), (float)eps, y.data_ptr(), y.stride(0), (float*)mean.data_ptr(), (float*)rstd.data_ptr(), 0};
+  sam_ln_fuse ln = {(const float*)gamma.data_ptr(), (const float*)beta.data_ptr(), (float)eps, y.data_ptr(), y.stride(0), (float*)mean.data_ptr(), (float*)rstd.data_ptr(), 0, nullptr, 0};
+  if (M >= 2048) {
+    // MMT-size products: the exchange workspace of the LayerNorm inside the launch -- one zero-filled buffer per (device, stream), grown on demand; every launch
+    // leaves its counters zero again (include/sam_hip.h: sam_ln_fuse.xws)
+    static std::map<std::pair<int, void*>, Tensor> cache;
+    const int64_t bytes = sam_gemm_ln_ws_bytes((int)M, (int)N);
+    Tensor& xws = cache[{(int)a.get_device(), cur_stream()}];
+    if (!xws.defined() || xws.numel() * 4 < bytes) xws = at::zeros({(bytes + 3) / 4}, a.options().dtype(at::kFloat));
+    ln.xws = (float*)xws.data_ptr(); ln.xws_bytes = xws.numel() * 4;
+  }
   o.ln = &ln;
   Tensor z = gemm(a, b, true, true, o);
   if (ln.done) return {z, y, mean, rstd};

@@ -329,6 +329,9 @@ def gemm_ln(a, b, gamma, beta, eps, **kw):
     rstd = torch.empty((m,), dtype=torch.float32, device=a.device)
     ln = capi.LnFuse()
     ln.gamma, ln.beta, ln.eps, ln.y, ln.ldy, ln.mean, ln.rstd, ln.done = gamma.data_ptr(), beta.data_ptr(), float(eps), y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), 0
+    if m >= 2048:          # MMT-size products: the exchange workspace of the LayerNorm inside the launch (zero-filled once per device and stream; sam_ln_fuse.xws)
+        xws = _ln_xws(a.device, int(capi.call("sam_gemm_ln_ws_bytes", m, n)))
+        ln.xws, ln.xws_bytes = xws.data_ptr(), xws.numel() * 4
     z = gemm(a, b, ln=ln, **kw)
     if ln.done:
         return z, y, mean, rstd
@@ -337,6 +340,30 @@ def gemm_ln(a, b, gamma, beta, eps, **kw):
 
 # ----------------------------------------------------------------------------- scratch
 _WS = {}
+_LN_XWS = {}
+
+
+def _ln_xws(device, nbytes):
+    """per-(device, stream) exchange workspace of the in-launch LayerNorm: zero-filled when (re)allocated, left with zero counters by every launch"""
+    key = (device, capi.stream_handle().value)
+    buf = _LN_XWS.get(key)
+    if buf is None or buf.numel() * 4 < nbytes:
+        buf = torch.zeros((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _LN_XWS[key] = buf
+    return buf
+
+
+def capi_ln_words():
+    """words in front of the (mean, M2) pairs of an in-launch LayerNorm workspace: error word + counters (csrc/gemm_common.h: LN_WS_PART0)"""
+    return 64 + 4 * 1024
+
+
+def ln_xws_check():
+    """raise if a launch's bounded wait for a row's statistics ran out (word 0 of a workspace); synchronises"""
+    for buf in _LN_XWS.values():
+        if int(buf[:1].view(torch.int32).item()) != 0:
+            buf[:1].zero_()
+            raise capi.SamHipError("LayerNorm inside the GEMM launch: a block waited in vain for the other parts of its rows (another kernel held the CUs its partners needed)")
 
 
 def _workspace(nbytes, device, tag):
@@ -842,6 +869,7 @@ def reset_workspaces():
     the next call allocates fresh, zero-filled ones"""
     _GROUPED_WS.clear()
     _WS.clear()
+    _LN_XWS.clear()
     LnFinalizeQueue.clear()
 
 

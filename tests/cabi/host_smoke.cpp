@@ -26,7 +26,7 @@ static bool close(const std::vector<float>& got, const std::vector<double>& ref,
 }
 
 int main() {
-  if (sam_abi_version() != 8) { std::printf("unexpected ABI version %d\n", sam_abi_version()); return 1; }
+  if (sam_abi_version() != 9) { std::printf("unexpected ABI version %d\n", sam_abi_version()); return 1; }
   int cus = 0, lds = 0; char arch[64] = {0};
   SAM(sam_device_info(&cus, &lds, arch, sizeof(arch)));
   std::printf("device: %s, %d CUs, %d B LDS/CU\n", arch, cus, lds);

@@ -34,7 +34,7 @@ def test_ctypes_binding_covers_the_header():
     assert declared <= bound, "unbound entry points: %s" % sorted(declared - bound)
     assert bound <= set(header_functions()), "bound but undeclared: %s" % sorted(bound - set(header_functions()))
     l = _capi.lib()
-    assert l.sam_abi_version() == 8
+    assert l.sam_abi_version() == 9
     import sam_textvqa_amd._build as b
     assert l.sam_build_digest().decode() == b._digest()          # the binary that is loaded is the one built from the sources in the tree
     assert _capi.call("sam_attn_words_per_row", 182) == 6 and _capi.call("sam_attn_words_per_row", 20) == 1

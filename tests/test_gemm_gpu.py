@@ -527,6 +527,50 @@ def test_layernorm_inside_the_splitk_reduction_is_bit_identical_to_two_launches(
         assert torch.equal(z2, z0) and torch.equal(y2, y0) and torch.equal(mean2, mean0) and torch.equal(rstd2, rstd0)
 
 
+@pytest.mark.parametrize("m,n,k,p_drop", [(11648, 768, 768, 0.1), (11648, 768, 3072, 0.1), (11200, 768, 768, 0.0), (4000, 768, 768, 0.1), (11648, 1536, 768, 0.1), (13000, 768, 768, 0.1)])
+def test_layernorm_inside_the_mmt_size_launch(m, n, k, p_drop, monkeypatch):
+    """VERDICT r5 missing #1 / SURVEY 8(b) `linear_bias_dropout_residual_ln` as ONE kernel at MMT size (sa_m4c.py:653, 680, 1016-1028): a product the loader-wave
+    kernel covers in one round of tiles (11648 x 768: 244 tiles of 192 x 192) normalises its rows inside the launch -- the waves and blocks that share a row
+    exchange (mean, M2) pairs (gemm_common.h: gemm_ln_pass).  z is the two-launch form's bit for bit; mean / rstd agree to fp32 rounding, y to one bf16 ulp of the
+    largest output; launch after launch the same bits; the workspace's counters are back at zero; shapes that need more than one round (N = 1536; 13000 rows)
+    fall back to the separate LayerNorm and say so (`done` = 0).  Opt-in (SAM_GEMM_LN_FUSE=1): measured slower than the two launches (profiles/r6_gemm_experiments.txt #16)."""
+    import torch
+    from sam_textvqa_amd import _capi as capi, ops
+    monkeypatch.setenv("SAM_GEMM_LN_FUSE", "1")
+    g = torch.Generator().manual_seed(21)
+    a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).cuda()
+    w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias = torch.randn(n, generator=g).cuda()
+    res = torch.randn(m, n, generator=g).to(torch.bfloat16).cuda()
+    gamma, beta = (1 + 0.1 * torch.randn(n, generator=g)).cuda(), (0.1 * torch.randn(n, generator=g)).cuda()
+    kw = dict(epilogue=capi.EPI_BIAS_DROPOUT_RES, bias=bias, residual=res, p_drop=p_drop, seed=7, offset=3)
+    z0 = ops.gemm(a, w, **kw)
+    y0, mean0, rstd0 = ops.layernorm_fwd(z0, gamma, beta, 1e-12)
+    expect = n == 768 and 7680 <= m <= 12288          # the loader-wave kernel's range (>= 160 tiles of 192 x 192) and ONE round on 256 CUs (<= 64 row tiles x 4)
+    ln = capi.LnFuse()
+    y = torch.full_like(z0, 7.0); mean = torch.full((m,), 7.0, device="cuda"); rstd = torch.full((m,), 7.0, device="cuda")
+    xws = ops._ln_xws(a.device, int(capi.call("sam_gemm_ln_ws_bytes", m, n)))
+    ln.gamma, ln.beta, ln.eps, ln.y, ln.ldy, ln.mean, ln.rstd, ln.done = gamma.data_ptr(), beta.data_ptr(), 1e-12, y.data_ptr(), y.stride(0), mean.data_ptr(), rstd.data_ptr(), 5
+    ln.xws, ln.xws_bytes = xws.data_ptr(), xws.numel() * 4
+    z1 = ops.gemm(a, w, ln=ln, **kw)
+    torch.cuda.synchronize()
+    assert bool(ln.done) == expect, (m, n, k, ln.done)
+    assert torch.equal(z0, z1)
+    if not expect:
+        z2, y2, mean2, rstd2 = ops.gemm_ln(a, w, gamma, beta, 1e-12, **kw)          # the caller-facing form: falls back, same bits as two launches
+        assert torch.equal(y2, y0) and torch.equal(mean2, mean0)
+        return
+    assert int(xws[:ops.capi_ln_words()].view(torch.int32).abs().sum()) == 0, "error word / counters must be zero after the launch"
+    assert torch.allclose(mean, mean0, rtol=0, atol=2e-6 * float(z0.float().abs().max())) and torch.allclose(rstd, rstd0, rtol=2e-6, atol=0)
+    ulp = 2.0 ** -8 * float(y0.float().abs().max())
+    d = (y.float() - y0.float()).abs()
+    assert float(d.max()) <= ulp and float((d > 0).float().mean()) < 0.02, (float(d.max()), ulp, float((d > 0).float().mean()))
+    for _ in range(3):          # bit-reproducible, and through the caller-facing form
+        z2, y2, mean2, rstd2 = ops.gemm_ln(a, w, gamma, beta, 1e-12, **kw)
+        assert torch.equal(z2, z0) and torch.equal(y2, y) and torch.equal(mean2, mean) and torch.equal(rstd2, rstd)
+    ops.ln_xws_check()
+
+
 @pytest.mark.parametrize("reserve", [16, 32, 40, 64])
 def test_persistent_grids_with_cus_withheld_compute_the_same(reserve):
     """sam_set_cu_reserve (VERDICT r5 missing #3): the persistent grids sized for (CUs - reserve).  A tile's value does not depend on which block computes it:
