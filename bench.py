@@ -736,6 +736,13 @@ def main():
             res["speedup_vs_eager_rocm_fp32"] = round(res["value"] / v, 2)
     if world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(args.context, layers, args.vocab)
+    try:
+        # RCCL writes its version banner ("RCCL version : ...", five lines, rank 0) through C stdio at communicator creation; with stdout redirected that buffer is
+        # flushed at exit, i.e. BEHIND the line below: the JSON line must be the last thing this command prints
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
     print(json.dumps(res), flush=True)
     if parallel.dist.is_initialized():
         parallel.dist.barrier()

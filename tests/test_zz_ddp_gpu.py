@@ -161,6 +161,8 @@ def test_bench_under_torch_distributed_run_one_rank_with_reducer_check(payload):
     assert out["n_gpus"] == 1 and out["steps"] == 4 and out["scaling"] == "weak" and out["value"] > 0
     assert "exposed_comm_ms" in out and out["exposed_comm_ms"] >= 0.0
     assert out.get("dp_transport") == "rccl-direct"
+    # the JSON line is the LAST line of stdout (RCCL's version banner, buffered in C stdio since the communicator was built, is flushed in front of it)
+    assert [l for l in r.stdout.splitlines() if l.strip()][-1].startswith("{"), r.stdout[-400:]
 
 
 def test_bench_under_torch_distributed_run_two_ranks_on_one_gpu():
