@@ -661,14 +661,14 @@ def test_persistent_decoding_kernel_at_other_sequence_lengths(shapes, monkeypatc
     err = ((a[0] - b[0]).abs()[live].max() / a[0][live].abs().max()).item()
     assert torch.equal(a[1], b[1]) and err < 6e-3, (sum(shapes), err)
     from sam_textvqa_amd.synthetic import clone_batch
-    # the fp32 oracle's greedy loop runs on the host (its cost is this test's cost): the first 3 of the 5 samples -- samples are independent
+    # the fp32 oracle's greedy loop runs on the host (its cost is this test's cost): the first 2 of the 5 samples -- samples are independent
     full = _batch(5, shapes, vocab, 41, "cpu")
-    first = {k: (v[:3].clone() if torch.is_tensor(v) else {kk: vv[:3].clone() for kk, vv in v.items()}) for k, v in full.items()}
+    first = {k: (v[:2].clone() if torch.is_tensor(v) else {kk: vv[:2].clone() for kk, vv in v.items()}) for k, v in full.items()}
     with torch.no_grad():
         want = ref.eval()(clone_batch(first))["textvqa_scores"].float()
     live = want > -9000
-    e2 = ((b[0][:3] - want).abs()[live].max() / want[live].abs().max()).item()
-    assert e2 < 6e-3 and torch.equal(want.argmax(-1)[:, :-1], b[1][:3, 1:]), (sum(shapes), e2)
+    e2 = ((b[0][:2] - want).abs()[live].max() / want[live].abs().max()).item()
+    assert e2 < 6e-3 and torch.equal(want.argmax(-1)[:, :-1], b[1][:2, 1:]), (sum(shapes), e2)
 
 
 def test_persistent_decoding_kernel_failure_falls_back_to_the_per_kernel_step(monkeypatch):

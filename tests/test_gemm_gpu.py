@@ -304,15 +304,19 @@ def test_grouped_wgrad_matches_individual():
         ops.wgrad_grouped(jobs * 6)         # more than 20 problems
 
 
-def _wgrad_jobs(R, shapes, seed0=0, bias=(1, 3)):
+def _wgrad_jobs(R, shapes, seed0=0, bias=(1, 3), want_ref=True):
+    """(jobs, refs): refs = the plain PyTorch fp32 products of the same bf16 operands (torch.matmul in fp32 on the device, TF32 off: on the pool's slower hosts the
+    CPU matmuls of these 8-20 problem sets were most of the tests' wall time); None when the caller only wants the jobs"""
     jobs, refs = [], []
+    torch.backends.cuda.matmul.allow_tf32 = False
     for j, (m, n) in enumerate(shapes):
-        dy, x = rnd((R, m), seed0 + 30 + j), rnd((R, n), seed0 + 40 + j)
-        base = torch.randn(m, n, generator=torch.Generator().manual_seed(seed0 + 50 + j))
+        dy, x = rnd((R, m), seed0 + 30 + j).cuda(), rnd((R, n), seed0 + 40 + j).cuda()
+        base = torch.randn(m, n, generator=torch.Generator().manual_seed(seed0 + 50 + j)).cuda()
         db = torch.full((m,), 0.25, device="cuda") if j in bias else None
-        jobs.append((dy.cuda(), x.cuda(), base.clone().cuda(), db))
-        refs.append((base + dy.float().t() @ x.float(), None if db is None else 0.25 + dy.float().sum(0)))
-    return jobs, refs
+        jobs.append((dy, x, base.clone(), db))
+        if want_ref:
+            refs.append((base + dy.float().t() @ x.float(), None if db is None else 0.25 + dy.float().sum(0)))
+    return jobs, (refs if want_ref else None)
 
 
 @pytest.mark.parametrize("R", [1024, 1088, 4480])
@@ -333,12 +337,12 @@ def test_grouped_wgrad_eight_wave_pair_exchange(R):
     assert int(ws[:216].view(torch.int32).abs().sum()) == 0, "pair flags must be consumed"
     first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in jobs]
     for _ in range(3):                                   # same inputs, fresh accumulators: bit-identical results, launch after launch
-        again, _ = _wgrad_jobs(R, shapes)
+        again, _ = _wgrad_jobs(R, shapes, want_ref=False)
         ops.wgrad_grouped(again, force_tile=1256)
         for (a, b), j in zip(first, again):
             assert torch.equal(a, j[2])
             assert b is None or torch.equal(b, j[3])
-    old, _ = _wgrad_jobs(R, shapes)
+    old, _ = _wgrad_jobs(R, shapes, want_ref=False)
     ops.wgrad_grouped(old, force_tile=128)               # the 4-wave kernel: same products, fp32 sums in another order
     for (a, b), j in zip(first, old):
         assert float((a - j[2]).abs().max()) <= 2e-4 * (1.0 + float(j[2].abs().max()))
@@ -351,7 +355,7 @@ def test_grouped_wgrad_overwrite_equals_accumulate_into_zero(R, force):
     (the Trainer leaves the encoder layers' gradients un-zeroed and lets their backward overwrite them).  Both grouped kernels."""
     ops, capi = _mods()
     shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
-    jobs, _ = _wgrad_jobs(R, shapes)
+    jobs, _ = _wgrad_jobs(R, shapes, want_ref=False)
     zero = [(dy, x, torch.zeros_like(dw), None if db is None else torch.zeros_like(db)) for dy, x, dw, db in jobs]
     ops.wgrad_grouped(zero, force_tile=force)
     junk = [(dy, x, torch.full_like(dw, 7.5), None if db is None else torch.full_like(db, -3.0)) for dy, x, dw, db in jobs]
@@ -375,8 +379,8 @@ def test_grouped_wgrad_mixed_depths_in_one_launch():
         assert_close_bf16(dw, rw, ulps=0, name="mixed-depth grouped wgrad")
         if db is not None:
             assert_close_bf16(db, rb, ulps=0, name="mixed-depth grouped bias grad")
-    d2, _ = _wgrad_jobs(2048, shapes * 2, seed0=100, bias=(0, 3, 5))
-    s2, _ = _wgrad_jobs(320, shapes * 3, seed0=200, bias=(1, 2, 7, 11))
+    d2, _ = _wgrad_jobs(2048, shapes * 2, seed0=100, bias=(0, 3, 5), want_ref=False)
+    s2, _ = _wgrad_jobs(320, shapes * 3, seed0=200, bias=(1, 2, 7, 11), want_ref=False)
     ops.wgrad_grouped(d2, force_tile=1256)
     ops.wgrad_grouped(s2, force_tile=1256)
     for a, b in zip(deep + shal, d2 + s2):
@@ -428,12 +432,12 @@ def test_grouped_wgrad_loader_wave_kernel_pair_slices_and_shallow_tiles(R):
             assert_close_bf16(db, rb, ulps=0, name="loader-wave grouped bias grad")
     first = [(j[2].clone(), None if j[3] is None else j[3].clone()) for j in deep]
     for _ in range(3):                                    # fresh accumulators, same inputs: bit-identical, launch after launch (also: counters really returned to zero)
-        again, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6))
+        again, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6), want_ref=False)
         ops.wgrad_grouped(again, force_tile=12448)
         for (a, b), j in zip(first, again):
             assert torch.equal(a, j[2]) and (b is None or torch.equal(b, j[3]))
     ops.grouped_ws_check()
-    old, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6))
+    old, _ = _wgrad_jobs(R, shapes * 2, seed0=500, bias=(0, 1, 3, 5, 6), want_ref=False)
     ops.wgrad_grouped(old, force_tile=1256)               # the 8-wave kernel: same products, fp32 sums in another order
     for (a, b), j in zip(first, old):
         assert float((a - j[2]).abs().max()) <= 2e-4 * (1.0 + float(j[2].abs().max()))
@@ -455,7 +459,7 @@ def test_grouped_wgrad_loader_wave_kernel_pair_slices_and_shallow_tiles(R):
         assert torch.equal(a[2], b[2]) and (a[3] is None or torch.equal(a[3], b[3]))
     ops.grouped_ws_check()
     # a set with fewer deep tiles than CUs is not one for this kernel: forcing it is an error, the default goes to the 8-wave kernel
-    one, _ = _wgrad_jobs(R, shapes)
+    one, _ = _wgrad_jobs(R, shapes, want_ref=False)
     with pytest.raises(capi.SamHipError):
         ops.wgrad_grouped(one, force_tile=12448)
 
@@ -470,7 +474,7 @@ def test_grouped_wgrad_eight_wave_ragged_and_unsplit():
             assert_close_bf16(dw, rw, ulps=0, name="8-wave grouped wgrad %s" % (shapes,))
             if db is not None:
                 assert_close_bf16(db, rb, ulps=0, name="8-wave grouped bias grad %s" % (shapes,))
-    jobs, _ = _wgrad_jobs(1456, [(768, 768)])           # K % 64 != 0: not a problem for this kernel; forcing it is an error, the default falls back
+    jobs, _ = _wgrad_jobs(1456, [(768, 768)], want_ref=False)           # K % 64 != 0: not a problem for this kernel; forcing it is an error, the default falls back
     with pytest.raises(capi.SamHipError):
         ops.wgrad_grouped(jobs, force_tile=1256)
     ops.wgrad_grouped(jobs)
