@@ -679,10 +679,14 @@ def rowvec(mode, a, b=None, vec=None):
     if a.dim() != 2 or a.stride(1) != 1:
         raise capi.SamHipError("rowvec: a must be 2-D with contiguous rows")
     if m == 0:
+        if b is None:
+            raise capi.SamHipError("rowvec mul: the second operand is missing")
         _chk(b, BF16, "b")
         if b.shape != a.shape or b.stride(1) != 1:
             raise capi.SamHipError("rowvec mul: b must have a's shape and contiguous rows")
     else:
+        if vec is None:
+            raise capi.SamHipError("rowvec %s: the fp32 vector is missing" % mode)
         _chk(vec, torch.float32, "vec")
         if vec.numel() != a.shape[1] or not vec.is_contiguous():
             raise capi.SamHipError("rowvec: vec must be a contiguous fp32 vector of a's width")
